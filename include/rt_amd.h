@@ -1,0 +1,194 @@
+/*
+ * rt_amd.h — C ABI of the MI355X (gfx950) path-trace backend for the
+ * I1Va/RayTracer per-pixel render path.
+ *
+ * The reference has no FFI of its own: its render entry point is the C++ method
+ *   void Camera::render(const SceneManager&, std::pair<int,int>, std::vector<RTPixelColor>&)
+ *   (reference inc/Camera.h:64-69, dispatch at src/Camera.cpp:56-67).
+ * Everything below sits *under* that method: the host layer flattens a
+ * SceneManager into the plain arrays declared here and calls rt_render_host().
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative rt_status otherwise, and
+ *     never throws; rt_last_error() gives a printable reason.  (The reference
+ *     uses assert()/silent clamps only, src/Camera.cpp:76-77.)
+ *   - one context per device; a context is not re-entrant.
+ *   - plain pointers and sizes only; "d_" arguments are DEVICE pointers valid on
+ *     the context's device, "h_" arguments are HOST pointers.
+ *   - the library never falls back to a CPU renderer: scenes it cannot render
+ *     are rejected with RT_ERR_UNSUPPORTED.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument (null pointer, non-positive size, ...) */
+    RT_ERR_HIP = -2,         /* a HIP runtime call failed; see rt_last_error()      */
+    RT_ERR_UNSUPPORTED = -3, /* feature outside the path this backend renders      */
+    RT_ERR_STATE = -4        /* scene or camera not uploaded yet                   */
+} rt_status;
+
+/* Material kinds: the four RTMaterial subclasses, reference inc/RTMaterial.h:63,98,135,200. */
+enum {
+    RT_MAT_LAMBERTIAN = 0,
+    RT_MAT_METAL = 1,
+    RT_MAT_DIELECTRIC = 2,
+    RT_MAT_EMISSIVE = 3
+};
+
+/* One sphere: SphereObject::position_ + radius_ (reference inc/RTObjects.h:31,86).
+ * The radius may be negative (hollow-glass trick: the outward normal flips,
+ * inc/RTObjects.h:154). */
+typedef struct rt_sphere {
+    float cx, cy, cz, r;
+} rt_sphere;
+
+/* One material, flattened.
+ *   albedo   : RTLambertian::diffuse_ / RTMetal::specular_ / RTDielectric::specular_local_
+ *              (the colour scatter() returns as attenuation, inc/RTMaterial.h:78,113,147)
+ *   fuzz     : RTMetal::fuzz_ (already clamped to <= 1 by the constructor, :103)
+ *   ior      : RTDielectric::refractionIndex_ (:137)
+ *   emission : RTMaterial::emission_ — honoured for every kind, as emitted() is (:37)
+ */
+typedef struct rt_material {
+    uint32_t type;
+    float albedo[3];
+    float fuzz;
+    float ior;
+    float emission[3];
+    float _pad;
+} rt_material;
+
+/* Camera state the kernels need: Camera::center_ and the three Viewport vectors
+ * produced by Camera::updateViewPort (reference src/Camera.cpp:206-221,
+ * inc/Camera.h:24-33).  The viewport is always 1x1 at focal length 1. */
+typedef struct rt_camera {
+    float center[3];
+    float upper_left[3];
+    float right[3];
+    float down[3];
+} rt_camera;
+
+/* Render flags */
+enum {
+    RT_FLAG_ACCUMULATE = 1u << 0 /* add to d_accum instead of overwriting it; the
+                                    8-bit image is then made from the running mean */
+};
+
+/* Render request: CameraRenderProperties (inc/Camera.h:14-22) plus the frame
+ * geometry and the strip partition used for multi-GPU rendering.
+ *
+ * The image is cut into strips of RT_STRIP_ROWS rows.  A call renders strips
+ * strip_first, strip_first + strip_stride, ... and stores them *compactly*:
+ * local strip k (global strip strip_first + k*strip_stride) occupies rows
+ * [k*RT_STRIP_ROWS, (k+1)*RT_STRIP_ROWS) of the output buffers, each row `width`
+ * pixels.  With strip_first = 0, strip_stride = 1 the output is the plain
+ * row-major width x height image.  Random streams are keyed on the *global*
+ * pixel id y*width + x, so any partition produces the same bytes.
+ */
+#define RT_STRIP_ROWS 8
+
+typedef struct rt_params {
+    int32_t width;
+    int32_t height;
+    int32_t samples_per_pixel; /* CameraRenderProperties::samplesPerPixel              */
+    int32_t max_depth;         /* CameraRenderProperties::maxRayDepth                  */
+    int32_t sample_offset;     /* index of the first sample (progressive rendering)   */
+    uint32_t seed;
+    uint32_t flags;
+    int32_t strip_first;
+    int32_t strip_stride;
+} rt_params;
+
+/* Number of rows the compact output of `p` holds (multiple of RT_STRIP_ROWS unless
+ * strip_stride == 1, where it is exactly height). */
+int rt_output_rows(const rt_params *p);
+
+/* Replaces: nothing in the reference (it has no device); creates the per-device
+ * state that Camera::render would otherwise keep on the stack. */
+int rt_create(int device, rt_ctx **out);
+void rt_destroy(rt_ctx *ctx);
+const char *rt_last_error(const rt_ctx *ctx);
+
+/* Replaces SceneManager's primitive list as seen by hitClosest
+ * (reference src/RayTracer.cpp:68-82, container inc/RayTracer.h:9,29-32).
+ * Sphere order = insertion order = tie-break order.  mat_id[i] indexes mats[]. */
+int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_spheres,
+                    const uint32_t *h_mat_id, int n_mats, const rt_material *h_mats);
+
+/* Replaces Camera::center()/viewPort() reads inside genRay (src/Camera.cpp:124-135). */
+int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
+
+/* Replaces Camera::renderParallel (reference src/Camera.cpp:69-88) together with
+ * renderPixelColor/genRay/getRayColor/convertRTColor (:105-157, :19-34) and
+ * SceneManager::hitClosest / SphereObject::hit / RTMaterial::scatter beneath them.
+ *   d_rgba  : device, rt_output_rows()*width RGBA8 pixels (RTPixelColor, inc/Camera.h:10-12)
+ *   d_accum : device, optional (may be NULL), rt_output_rows()*width float4
+ *             (sum r, sum g, sum b, number of samples)
+ *   d_rays  : device, optional, one uint64 that the call ADDS the number of
+ *             closest-hit queries to
+ *   stream  : a hipStream_t (NULL = the default stream).  The call is asynchronous.
+ */
+int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum,
+              uint64_t *d_rays, void *stream);
+
+/* Same, with HOST outputs and a synchronous copy-out: this is the function a
+ * Camera::render binding calls with outputBufer.data().  h_rays receives (is
+ * overwritten with) the number of closest-hit queries. */
+int rt_render_host(rt_ctx *ctx, const rt_params *p, uint8_t *h_rgba, float *h_accum,
+                   uint64_t *h_rays);
+
+/* First-hit flags */
+enum {
+    RT_FH_REFINE = 1u << 0 /* re-test numerically ambiguous rays in fp64 so that the
+                              returned id equals a double-precision evaluation */
+};
+
+/* Replaces SceneManager::hitClosest(ray, Interval(tmin, +inf), rec, false)
+ * (reference src/RayTracer.cpp:68-82) for a batch of rays.
+ *   org, dir : n_rays x 3 floats (directions need not be unit length,
+ *              inc/RTObjects.h:136)
+ *   id       : index of the closest sphere or -1;  t: HitRecord::time;
+ *   normal   : HitRecord::normal (unit, facing against the ray);
+ *   front    : HitRecord::frontFace (0/1).  t/normal/front may be NULL.
+ * Host-pointer version (copies in and out, synchronous). */
+int rt_first_hit_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir,
+                      float tmin, uint32_t flags, int32_t *h_id, float *h_t,
+                      float *h_normal, uint8_t *h_front);
+
+/* Device-pointer version, asynchronous on `stream`. */
+int rt_first_hit(rt_ctx *ctx, int n_rays, const float *d_org, const float *d_dir,
+                 float tmin, uint32_t flags, int32_t *d_id, float *d_t, float *d_normal,
+                 uint8_t *d_front, void *stream);
+
+/* Replaces RTMaterial::scatter (reference inc/RTMaterial.h:67-80,105-115,142-170,
+ * 205-207) for a batch of hits, with the three uniform variates the bounce would
+ * draw passed in explicitly (u[0],u[1] -> IVec3f::randomUnit, u[2] -> randomDouble).
+ * Host pointers, synchronous.  All arrays are n x 3 floats except mat (n),
+ * front (n) and scattered_flag (n).  Used by parity tests of the bounce step. */
+int rt_scatter_host(rt_ctx *ctx, int n, const uint32_t *h_mat, const float *h_in_dir,
+                    const float *h_point, const float *h_normal, const uint8_t *h_front,
+                    const float *h_u, float *h_att, float *h_out_org, float *h_out_dir,
+                    uint8_t *h_scattered_flag);
+
+/* The counter-based generator the kernels use, exposed for tests:
+ * fills out[4] with the four 32-bit words of stream (pixel, sample, call, seed). */
+void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint32_t out[4]);
+
+/* Library/ABI version (major*100 + minor). */
+int rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,133 @@
+"""ctypes loader for the CPU oracle (oracle/rt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg — never by the raytracer_amd package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+SPHERE_DTYPE = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("r", "<f4")])
+MATERIAL_DTYPE = np.dtype(
+    [("type", "<u4"), ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4"), ("emission", "<f4", 3), ("_pad", "<f4")]
+)
+CAMERA_DTYPE = np.dtype([("center", "<f4", 3), ("upper_left", "<f4", 3), ("right", "<f4", 3), ("down", "<f4", 3)])
+
+
+def build(force: bool = False):
+    """Compile both oracle libraries (a few seconds)."""
+    if force or not all(os.path.exists(os.path.join(_HERE, n)) for n in ("liborc_f64.so", "liborc_f32.so")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Oracle:
+    def __init__(self, precision: str = "f64"):
+        path = os.path.join(_HERE, f"liborc_{precision}.so")
+        if not os.path.exists(path):
+            build()
+        self.lib = C.CDLL(path)
+        L = self.lib
+        vp, i32, u32 = C.c_void_p, C.c_int, C.c_uint32
+        L.orc_rng4.argtypes = [u32, u32, u32, u32, C.POINTER(u32)]
+        L.orc_render.argtypes = [i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, u32, i32, i32, i32, i32, vp, vp]
+        L.orc_render.restype = C.c_uint64
+        L.orc_first_hit.argtypes = [i32, vp, i32, vp, vp, C.c_double, vp, vp, vp, vp, vp]
+        L.orc_scatter.argtypes = [i32] + [vp] * 11
+        L.orc_sample_radiance.argtypes = [i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, u32, i32, vp]
+        L.orc_primary_rays.argtypes = [vp, i32, i32, u32, i32, i32, vp, vp]
+        L.orc_update_viewport.argtypes = [vp, vp, vp]
+        L.orc_convert_color.argtypes = [vp, vp]
+        L.orc_refract_clamped.restype = C.c_long
+        L.orc_real_bytes.restype = C.c_int
+        self.precision = precision
+
+    # -- helpers ------------------------------------------------------------
+    @staticmethod
+    def _scene_args(scene):
+        sph = np.ascontiguousarray(scene.spheres, dtype=SPHERE_DTYPE)
+        mid = np.ascontiguousarray(scene.mat_id, dtype=np.uint32)
+        mats = np.ascontiguousarray(scene.mats, dtype=MATERIAL_DTYPE)
+        cam = np.ascontiguousarray(scene.camera, dtype=CAMERA_DTYPE)
+        return sph, mid, mats, cam
+
+    def rng4(self, pixel, sample, call, seed):
+        out = (C.c_uint32 * 4)()
+        self.lib.orc_rng4(pixel, sample, call, seed, out)
+        return np.array(list(out), dtype=np.uint32)
+
+    def render(self, scene, W, H, spp, max_depth, seed=0, samples_per_scatter=1, sample_offset=0,
+               iterative=False, y0=0, y1=None, want_accum=True):
+        sph, mid, mats, cam = self._scene_args(scene)
+        rgba = np.zeros((H, W, 4), np.uint8)
+        accum = np.zeros((H, W, 3), np.float64) if want_accum else None
+        rays = self.lib.orc_render(len(sph), _p(sph), _p(mid), len(mats), _p(mats), _p(cam), W, H, spp,
+                                   samples_per_scatter, max_depth, seed, sample_offset, 1 if iterative else 0,
+                                   y0, H if y1 is None else y1, _p(rgba), _p(accum))
+        return rgba, accum, int(rays)
+
+    def first_hit(self, scene, org, dir, tmin=0.001, want_margin=False):
+        sph = np.ascontiguousarray(scene.spheres, dtype=SPHERE_DTYPE)
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, np.float32).reshape(-1, 3)
+        n = len(org)
+        ids = np.zeros(n, np.int32)
+        t = np.zeros(n, np.float64)
+        nrm = np.zeros((n, 3), np.float64)
+        front = np.zeros(n, np.uint8)
+        margin = np.zeros(n, np.float64) if want_margin else None
+        self.lib.orc_first_hit(len(sph), _p(sph), n, _p(org), _p(dir), float(tmin), _p(ids), _p(t), _p(nrm),
+                               _p(front), _p(margin))
+        return ids, t, nrm, front, margin
+
+    def scatter(self, mats, mat, in_dir, point, normal, front, u):
+        mats = np.ascontiguousarray(mats, dtype=MATERIAL_DTYPE)
+        mat = np.ascontiguousarray(mat, np.uint32)
+        f = lambda a: np.ascontiguousarray(a, np.float64).reshape(-1, 3)
+        in_dir, point, normal, u = f(in_dir), f(point), f(normal), f(u)
+        front = np.ascontiguousarray(front, np.uint8)
+        n = len(mat)
+        att, oo, od = (np.zeros((n, 3)) for _ in range(3))
+        flag = np.zeros(n, np.uint8)
+        self.lib.orc_scatter(n, _p(mats), _p(mat), _p(in_dir), _p(point), _p(normal), _p(front), _p(u), _p(att),
+                             _p(oo), _p(od), _p(flag))
+        return att, oo, od, flag
+
+    def sample_radiance(self, scene, W, H, pid, smp, max_depth, seed=0, samples_per_scatter=1, iterative=False):
+        sph, mid, mats, cam = self._scene_args(scene)
+        out = np.zeros(3)
+        self.lib.orc_sample_radiance(len(sph), _p(sph), _p(mid), len(mats), _p(mats), _p(cam), W, H, pid, smp,
+                                     samples_per_scatter, max_depth, seed, 1 if iterative else 0, _p(out))
+        return out
+
+    def primary_rays(self, camera, W, H, seed=0, smp=0, jitter=False):
+        cam = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
+        org = np.zeros((W * H, 3), np.float32)
+        dir = np.zeros((W * H, 3), np.float32)
+        self.lib.orc_primary_rays(_p(cam), W, H, seed, smp, 1 if jitter else 0, _p(org), _p(dir))
+        return org, dir
+
+    def update_viewport(self, center, direction):
+        c = np.ascontiguousarray(center, np.float64)
+        d = np.ascontiguousarray(direction, np.float64)
+        cam = np.zeros(1, CAMERA_DTYPE)
+        self.lib.orc_update_viewport(_p(c), _p(d), _p(cam))
+        return cam
+
+    def convert_color(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.float64)
+        out = np.zeros(4, np.uint8)
+        self.lib.orc_convert_color(_p(rgb), _p(out))
+        return out
+
+    def refract_clamped(self):
+        return int(self.lib.orc_refract_clamped())

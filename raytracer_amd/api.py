@@ -1,0 +1,260 @@
+"""ctypes binding of the C ABI in include/rt_amd.h.
+
+There is no fallback: if the HIP library is missing or a call fails, an
+exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+STRIP_ROWS = 8
+FLAG_ACCUMULATE = 1
+FH_REFINE = 1
+
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
+
+# numpy views of the ABI structs
+SPHERE_DTYPE = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("r", "<f4")])
+MATERIAL_DTYPE = np.dtype(
+    [("type", "<u4"), ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4"), ("emission", "<f4", 3), ("_pad", "<f4")]
+)
+CAMERA_DTYPE = np.dtype([("center", "<f4", 3), ("upper_left", "<f4", 3), ("right", "<f4", 3), ("down", "<f4", 3)])
+assert SPHERE_DTYPE.itemsize == 16 and MATERIAL_DTYPE.itemsize == 40 and CAMERA_DTYPE.itemsize == 48
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("samples_per_pixel", C.c_int32),
+        ("max_depth", C.c_int32),
+        ("sample_offset", C.c_int32),
+        ("seed", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("strip_first", C.c_int32),
+        ("strip_stride", C.c_int32),
+    ]
+
+
+@dataclass
+class RenderParams:
+    """CameraRenderProperties (reference inc/Camera.h:14-22) + frame geometry + strip partition."""
+
+    width: int
+    height: int
+    samples_per_pixel: int = 3
+    max_depth: int = 10
+    sample_offset: int = 0
+    seed: int = 0
+    flags: int = 0
+    strip_first: int = 0
+    strip_stride: int = 1
+
+    def to_c(self) -> _Params:
+        return _Params(
+            self.width, self.height, self.samples_per_pixel, self.max_depth, self.sample_offset,
+            self.seed & 0xFFFFFFFF, self.flags, self.strip_first, self.strip_stride,
+        )
+
+
+EXPORTS = [
+    "rt_version", "rt_rng4", "rt_output_rows", "rt_create", "rt_destroy", "rt_last_error",
+    "rt_upload_scene", "rt_set_camera", "rt_render", "rt_render_host", "rt_first_hit",
+    "rt_first_hit_host", "rt_scatter_host",
+]
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """Load librt_amd.so and declare prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RtError(
+            f"HIP library not found at {p}: build it first (python -c 'import __graft_entry__ as g; g.build()')"
+        )
+    lib = C.CDLL(p)
+    vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
+    lib.rt_version.restype = C.c_int
+    lib.rt_rng4.argtypes = [u32, u32, u32, u32, C.POINTER(u32)]
+    lib.rt_rng4.restype = None
+    lib.rt_output_rows.argtypes = [C.POINTER(_Params)]
+    lib.rt_output_rows.restype = C.c_int
+    lib.rt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.rt_create.restype = C.c_int
+    lib.rt_destroy.argtypes = [vp]
+    lib.rt_destroy.restype = None
+    lib.rt_last_error.argtypes = [vp]
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_upload_scene.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
+    lib.rt_upload_scene.restype = C.c_int
+    lib.rt_set_camera.argtypes = [vp, vp]
+    lib.rt_set_camera.restype = C.c_int
+    lib.rt_render.argtypes = [vp, C.POINTER(_Params), vp, vp, vp, vp]
+    lib.rt_render.restype = C.c_int
+    lib.rt_render_host.argtypes = [vp, C.POINTER(_Params), vp, vp, C.POINTER(C.c_uint64)]
+    lib.rt_render_host.restype = C.c_int
+    lib.rt_first_hit.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp]
+    lib.rt_first_hit.restype = C.c_int
+    lib.rt_first_hit_host.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp]
+    lib.rt_first_hit_host.restype = C.c_int
+    lib.rt_scatter_host.argtypes = [vp, C.c_int] + [vp] * 10
+    lib.rt_scatter_host.restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def rng4(pixel: int, sample: int, call: int, seed: int) -> np.ndarray:
+    lib = load_library()
+    out = (C.c_uint32 * 4)()
+    lib.rt_rng4(pixel & 0xFFFFFFFF, sample & 0xFFFFFFFF, call & 0xFFFFFFFF, seed & 0xFFFFFFFF, out)
+    return np.array(list(out), dtype=np.uint32)
+
+
+def output_rows(p: RenderParams) -> int:
+    lib = load_library()
+    cp = p.to_c()
+    return int(lib.rt_output_rows(C.byref(cp)))
+
+
+class Renderer:
+    """One rendering context on one GPU (rt_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.rt_create(device, C.byref(h))
+        if rc != 0 or not h:
+            raise RtError(f"rt_create(device={device}) failed with status {rc} (is a GPU visible?)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.rt_last_error(self.h)
+            raise RtError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    # -- scene / camera -----------------------------------------------------
+    def upload_scene(self, spheres: np.ndarray, mat_id: np.ndarray, mats: np.ndarray):
+        spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        mat_id = np.ascontiguousarray(mat_id, dtype=np.uint32)
+        mats = np.ascontiguousarray(mats, dtype=MATERIAL_DTYPE)
+        if len(mat_id) != len(spheres):
+            raise RtError("mat_id and spheres differ in length")
+        self._check(
+            self.lib.rt_upload_scene(self.h, len(spheres), _ptr(spheres), _ptr(mat_id), len(mats), _ptr(mats)),
+            "rt_upload_scene",
+        )
+        self.n_spheres = len(spheres)
+
+    def set_camera(self, cam: np.ndarray):
+        cam = np.ascontiguousarray(cam, dtype=CAMERA_DTYPE).reshape(1)
+        self._check(self.lib.rt_set_camera(self.h, _ptr(cam)), "rt_set_camera")
+
+    def set_scene(self, scene):
+        """scene: a scenes.Scene"""
+        self.upload_scene(scene.spheres, scene.mat_id, scene.mats)
+        self.set_camera(scene.camera)
+
+    # -- render ---------------------------------------------------------------
+    def render_host(self, p: RenderParams, want_accum: bool = False, accum_in: np.ndarray | None = None):
+        """Render into host arrays.  Returns (rgba[rows,W,4] u8, accum[rows,W,4] f32 or None, rays)."""
+        rows = output_rows(p)
+        rgba = np.zeros((rows, p.width, 4), dtype=np.uint8)
+        accum = None
+        if accum_in is not None:
+            accum = np.ascontiguousarray(accum_in, dtype=np.float32).copy()
+        elif want_accum:
+            accum = np.zeros((rows, p.width, 4), dtype=np.float32)
+        rays = C.c_uint64(0)
+        cp = p.to_c()
+        self._check(
+            self.lib.rt_render_host(self.h, C.byref(cp), _ptr(rgba), _ptr(accum) if accum is not None else None,
+                                    C.byref(rays)),
+            "rt_render_host",
+        )
+        return rgba, accum, int(rays.value)
+
+    def render_device(self, p: RenderParams, rgba, accum=None, rays=None, stream=None):
+        """Asynchronous render into torch CUDA tensors (device pointers).
+
+        rgba: uint8 [rows, W, 4]; accum: float32 [rows, W, 4] or None; rays: int64 [1] or None."""
+        cp = p.to_c()
+        st = C.c_void_p(stream) if stream else None
+        self._check(
+            self.lib.rt_render(
+                self.h, C.byref(cp), C.c_void_p(rgba.data_ptr()),
+                C.c_void_p(accum.data_ptr()) if accum is not None else None,
+                C.c_void_p(rays.data_ptr()) if rays is not None else None, st,
+            ),
+            "rt_render",
+        )
+
+    # -- first hit / scatter --------------------------------------------------
+    def first_hit(self, org: np.ndarray, dir: np.ndarray, tmin: float = 0.001, refine: bool = False):
+        org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+        n = len(org)
+        ids = np.full(n, -2, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float32)
+        nrm = np.zeros((n, 3), dtype=np.float32)
+        front = np.zeros(n, dtype=np.uint8)
+        self._check(
+            self.lib.rt_first_hit_host(self.h, n, _ptr(org), _ptr(dir), float(tmin), FH_REFINE if refine else 0,
+                                       _ptr(ids), _ptr(t), _ptr(nrm), _ptr(front)),
+            "rt_first_hit_host",
+        )
+        return ids, t, nrm, front
+
+    def scatter(self, mat, in_dir, point, normal, front, u):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 3)
+        mat = np.ascontiguousarray(mat, dtype=np.uint32)
+        in_dir, point, normal, u = f(in_dir), f(point), f(normal), f(u)
+        front = np.ascontiguousarray(front, dtype=np.uint8)
+        n = len(mat)
+        att = np.zeros((n, 3), np.float32)
+        oo = np.zeros((n, 3), np.float32)
+        od = np.zeros((n, 3), np.float32)
+        flag = np.zeros(n, np.uint8)
+        self._check(
+            self.lib.rt_scatter_host(self.h, n, _ptr(mat), _ptr(in_dir), _ptr(point), _ptr(normal), _ptr(front),
+                                     _ptr(u), _ptr(att), _ptr(oo), _ptr(od), _ptr(flag)),
+            "rt_scatter_host",
+        )
+        return att, oo, od, flag

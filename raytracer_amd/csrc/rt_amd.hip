@@ -1,0 +1,801 @@
+// rt_amd.hip — HIP kernels (gfx950) and the C ABI declared in include/rt_amd.h.
+//
+// Render kernel layout
+//   * the image is cut into workgroup tiles of 32x8 pixels; a workgroup is four
+//     wavefronts, each owning one 8x8 pixel tile and the pool of
+//     (pixel, sample) work items of that tile;
+//   * a lane carries one path.  Every iteration all lanes of a wave scan the
+//     whole sphere list (brute force, spheres broadcast from LDS), then shade and
+//     bounce.  A lane whose path ended adds its radiance to the tile's fp32
+//     accumulator in LDS and takes the next work item of the pool; the new item
+//     indices come from a ballot + prefix count, so the wave stays full until
+//     the pool is empty;
+//   * when the pool is drained lane l tone-maps pixel l of the tile.
+// Scenes that fit the LDS budget are staged once; larger ones are streamed in
+// tiles shared by the whole workgroup.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <new>
+
+#include "../../include/rt_amd.h"
+#include "rt_device.h"
+
+using namespace rt;
+
+#define RT_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr int WG_THREADS = 256;
+constexpr int WAVES_PER_WG = 4;
+constexpr int WAVE_TILE = 8;                 // a wave owns WAVE_TILE x WAVE_TILE pixels
+constexpr int WG_TILE_W = WAVE_TILE * WAVES_PER_WG; // 32
+constexpr int WG_TILE_H = WAVE_TILE;         // 8 == RT_STRIP_ROWS
+constexpr int RESIDENT_MAX = 4096;           // spheres kept resident in LDS (64 KiB)
+constexpr int STREAM_TILE = 2048;            // spheres per streamed LDS tile (32 KiB)
+constexpr float TMIN = 0.001f;               // CLOSEST_HIT_MIN_T, src/Camera.cpp:10
+
+static_assert(WG_TILE_H == RT_STRIP_ROWS, "strip height must equal the workgroup tile height");
+
+struct KParams {
+    int width, height;
+    int spp, max_depth, sample_offset;
+    uint32_t seed, flags;
+    int strip_first, strip_stride;
+    int tiles_x;     // workgroup tiles per strip
+    int n_spheres;
+    float inv_w, inv_h;
+    float cam[12];   // center, upper_left, right, down
+};
+
+struct DeviceScene {
+    const float4 *sph;    // cx, cy, cz, r
+    const float4 *sph_r2; // cx, cy, cz, r*r  (what the scan loop reads)
+    const uint32_t *mat_id;
+    const DMat *mats;
+};
+
+// Scan spheres [0, cnt) of an LDS tile for one ray.
+__device__ __forceinline__ void scan_tile(const float4 *lds, int cnt, int base, V3 o, V3 d, float a, float inv_a,
+                                          float tmin, int self_id, float &best_t, int &best_id) {
+    int i = 0;
+#pragma unroll 1
+    for (; i + 4 <= cnt; i += 4) {
+        float4 s0 = lds[i], s1 = lds[i + 1], s2 = lds[i + 2], s3 = lds[i + 3];
+        test_sphere(o.x, o.y, o.z, d.x, d.y, d.z, a, inv_a, tmin, s0, base + i, self_id, best_t, best_id);
+        test_sphere(o.x, o.y, o.z, d.x, d.y, d.z, a, inv_a, tmin, s1, base + i + 1, self_id, best_t, best_id);
+        test_sphere(o.x, o.y, o.z, d.x, d.y, d.z, a, inv_a, tmin, s2, base + i + 2, self_id, best_t, best_id);
+        test_sphere(o.x, o.y, o.z, d.x, d.y, d.z, a, inv_a, tmin, s3, base + i + 3, self_id, best_t, best_id);
+    }
+    for (; i < cnt; ++i)
+        test_sphere(o.x, o.y, o.z, d.x, d.y, d.z, a, inv_a, tmin, lds[i], base + i, self_id, best_t, best_id);
+}
+
+// Camera::genRay, src/Camera.cpp:124-135: jittered point on the 1x1 viewport.
+__device__ __forceinline__ void gen_ray(const KParams &p, int px, int py, float u0, float u1, V3 &o, V3 &d) {
+    V3 c = mk(p.cam[0], p.cam[1], p.cam[2]);
+    V3 ul = mk(p.cam[3], p.cam[4], p.cam[5]);
+    V3 right = mk(p.cam[6], p.cam[7], p.cam[8]);
+    V3 down = mk(p.cam[9], p.cam[10], p.cam[11]);
+    float fx = ((float)px + u0) * p.inv_w;
+    float fy = ((float)py + u1) * p.inv_h;
+    V3 pt = madd(madd(ul, right, fx), down, fy);
+    o = c;
+    d = normalized(pt - c);
+}
+
+// One path's state, carried in registers.
+struct Path {
+    V3 o, d;
+    V3 T, L;      // throughput, radiance so far
+    float a, inv_a;
+    int pix;      // pixel index inside the wave tile, -1 = lane has no work
+    uint32_t gpix; // global pixel id (RNG key)
+    uint32_t sample;
+    uint32_t call; // RNG call index: 0 = ray generation, k = k-th bounce
+    int depth;    // closest-hit queries left
+    int self_id;  // sphere whose surface the ray starts on exactly (diffuse / metal bounce), else -1
+};
+
+template <bool STREAMED>
+__global__ __launch_bounds__(WG_THREADS) void render_kernel(KParams p, DeviceScene sc, uchar4 *__restrict__ rgba,
+                                                            float4 *__restrict__ accum,
+                                                            unsigned long long *__restrict__ rays_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [0, 3 KiB): per-wave accumulators, 4 waves x 64 pixels x 3 floats; then the sphere tile.
+    float *acc_all = reinterpret_cast<float *>(smem);
+    float4 *lds_sph = reinterpret_cast<float4 *>(smem + WAVES_PER_WG * 64 * 3 * sizeof(float));
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float *acc = acc_all + wave * 192;
+
+    // which tile
+    const int strip_local = blockIdx.x / p.tiles_x;
+    const int tile_x = blockIdx.x - strip_local * p.tiles_x;
+    const int strip = p.strip_first + strip_local * p.strip_stride;
+    const int x0 = tile_x * WG_TILE_W + wave * WAVE_TILE;
+    const int y0 = strip * WG_TILE_H;
+    const int vw = min(WAVE_TILE, p.width - x0);  // valid pixels in x (may be <= 0)
+    const int vh = min(WAVE_TILE, p.height - y0);
+    const int nvalid = (vw > 0 && vh > 0) ? vw * vh : 0;
+    const uint32_t pool = (uint32_t)nvalid * (uint32_t)p.spp;
+
+    acc[lane] = 0.f;
+    acc[lane + 64] = 0.f;
+    acc[lane + 128] = 0.f;
+
+    const int n = p.n_spheres;
+    if (!STREAMED) {
+        for (int i = threadIdx.x; i < n; i += WG_THREADS) lds_sph[i] = sc.sph_r2[i];
+    }
+    __syncthreads();
+
+    Path pt;
+    pt.pix = -1;
+    pt.o = pt.d = pt.T = pt.L = mk(0, 0, 0);
+    pt.a = pt.inv_a = 1.f;
+    pt.gpix = pt.sample = pt.call = 0;
+    pt.depth = 0;
+    pt.self_id = -1;
+    uint32_t next_item = 0; // wave-uniform
+    unsigned long long my_rays = 0;
+    bool need_work = true;
+
+    for (;;) {
+        // ---- hand out work items to lanes that need one (ballot + prefix count) ----
+        {
+            unsigned long long m = __ballot(need_work);
+            if (m) {
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                uint32_t item = next_item + rank;
+                next_item += (uint32_t)__popcll(m);
+                if (need_work) {
+                    if (item < pool) {
+                        uint32_t q = item % (uint32_t)nvalid;
+                        uint32_t smp = item / (uint32_t)nvalid;
+                        int lx = (int)(q % (uint32_t)vw), ly = (int)(q / (uint32_t)vw);
+                        pt.pix = ly * WAVE_TILE + lx;
+                        int px = x0 + lx, py = y0 + ly;
+                        pt.gpix = (uint32_t)(py * p.width + px);
+                        pt.sample = smp + (uint32_t)p.sample_offset;
+                        uint32_t w0, w1, w2, w3;
+                        rng4(pt.gpix, pt.sample, 0u, p.seed, w0, w1, w2, w3);
+                        gen_ray(p, px, py, u01(w0), u01(w1), pt.o, pt.d);
+                        pt.a = dot(pt.d, pt.d);
+                        pt.inv_a = 1.0f / pt.a;
+                        pt.T = mk(1, 1, 1);
+                        pt.L = mk(0, 0, 0);
+                        pt.call = 1;
+                        pt.depth = p.max_depth;
+                        pt.self_id = -1;
+                        need_work = false;
+                    } else {
+                        pt.pix = -1;
+                        need_work = false;
+                    }
+                }
+            }
+        }
+        const bool active = pt.pix >= 0 && pt.depth > 0;
+        // a path with depth 0 left (max_depth == 0) contributes black and ends at once
+        bool finished = pt.pix >= 0 && pt.depth <= 0;
+
+        if (STREAMED) {
+            if (!__syncthreads_or(active || finished)) break;
+        } else {
+            if (!__ballot(active || finished)) break;
+        }
+
+        // ---- closest hit over all spheres (SceneManager::hitClosest, src/RayTracer.cpp:77-82) ----
+        float best_t = __builtin_inff();
+        int best_id = -1;
+        if (STREAMED) {
+            for (int base = 0; base < n; base += STREAM_TILE) {
+                int cnt = min(STREAM_TILE, n - base);
+                __syncthreads();
+                for (int i = threadIdx.x; i < cnt; i += WG_THREADS) lds_sph[i] = sc.sph_r2[base + i];
+                __syncthreads();
+                if (active) scan_tile(lds_sph, cnt, base, pt.o, pt.d, pt.a, pt.inv_a, TMIN, pt.self_id, best_t, best_id);
+            }
+        } else {
+            if (active) scan_tile(lds_sph, n, 0, pt.o, pt.d, pt.a, pt.inv_a, TMIN, pt.self_id, best_t, best_id);
+        }
+
+        // ---- shade + bounce (Camera::getRayColor, src/Camera.cpp:137-157) ----
+        if (active) {
+            my_rays++;
+            pt.depth--;
+            if (pt.self_id >= 0)
+                self_hit(pt.o.x, pt.o.y, pt.o.z, pt.d.x, pt.d.y, pt.d.z, pt.inv_a, TMIN, sc.sph[pt.self_id],
+                         pt.self_id, best_t, best_id);
+            if (best_id < 0) {
+                pt.L = pt.L + pt.T * sky(pt.d);
+                finished = true;
+            } else {
+                float4 sph = sc.sph[best_id];
+                Hit h = finish_hit(pt.o, pt.d, best_t, sph);
+                const DMat &m = sc.mats[sc.mat_id[best_id]];
+                float4 at = m.albedo_type, ef = m.emission_fuzz;
+                float ior = m.ior_pad.x;
+                pt.L = pt.L + pt.T * mk(ef.x, ef.y, ef.z);
+                uint32_t w0, w1, w2, w3;
+                rng4(pt.gpix, pt.sample, pt.call, p.seed, w0, w1, w2, w3);
+                pt.call++;
+                V3 att, no, nd;
+                bool ok = scatter(__float_as_uint(at.w), mk(at.x, at.y, at.z), ef.w, ior, pt.d, h, u01(w0), u01(w1),
+                                  u01(w2), att, no, nd);
+                if (!ok || pt.depth == 0) {
+                    finished = true;
+                } else {
+                    pt.T = pt.T * att;
+                    pt.o = no;
+                    pt.d = nd;
+                    pt.a = dot(nd, nd);
+                    pt.inv_a = 1.0f / pt.a;
+                    // diffuse and metal bounces start exactly on the sphere; the dielectric nudges its origin
+                    pt.self_id = __float_as_uint(at.w) <= 1u ? best_id : -1;
+                }
+            }
+        }
+        if (finished) {
+            atomicAdd(&acc[pt.pix], pt.L.x);
+            atomicAdd(&acc[64 + pt.pix], pt.L.y);
+            atomicAdd(&acc[128 + pt.pix], pt.L.z);
+            pt.pix = -1;
+            need_work = true;
+        }
+    }
+
+    // ---- epilogue: lane l owns pixel l of the wave tile (convertRTColor, src/Camera.cpp:19-34) ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    {
+        int lx = lane & 7, ly = lane >> 3;
+        if (lx < vw && ly < vh) {
+            int px = x0 + lx;
+            int row = strip_local * WG_TILE_H + ly; // compact output row
+            if (p.strip_stride == 1) row = y0 + ly;
+            size_t o = (size_t)row * (size_t)p.width + (size_t)px;
+            float r = acc[lane], g = acc[64 + lane], b = acc[128 + lane];
+            float cnt = (float)p.spp;
+            if (accum) {
+                if (p.flags & RT_FLAG_ACCUMULATE) {
+                    float4 prev = accum[o];
+                    r += prev.x; g += prev.y; b += prev.z; cnt += prev.w;
+                }
+                accum[o] = make_float4(r, g, b, cnt);
+            }
+            float inv = 1.0f / cnt;
+            uchar4 px8;
+            px8.x = (unsigned char)to_byte(r * inv);
+            px8.y = (unsigned char)to_byte(g * inv);
+            px8.z = (unsigned char)to_byte(b * inv);
+            px8.w = 255;
+            rgba[o] = px8;
+        }
+    }
+    if (rays_out) {
+        // wave-level sum, one atomic per wave
+        for (int off = 32; off > 0; off >>= 1) my_rays += __shfl_down(my_rays, off, 64);
+        if (lane == 0 && my_rays) atomicAdd(rays_out, my_rays);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// First-hit kernel: SceneManager::hitClosest for a batch of rays
+// (src/RayTracer.cpp:68-82 with SphereObject::hit, inc/RTObjects.h:129-159).
+// ---------------------------------------------------------------------------
+
+// Double-precision restatement of hitDetail's decision for one sphere, evaluated
+// with separately rounded operations (no contraction) so that it reproduces a
+// host double evaluation bit for bit.
+#pragma clang fp contract(off)
+__device__ __noinline__ bool hit64(double ox, double oy, double oz, double dx, double dy, double dz, double tmin,
+                                   double tmax, double cx, double cy, double cz, double r, double &t_out) {
+    double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+    double a = dx * dx + dy * dy + dz * dz;
+    double hb = ocx * dx + ocy * dy + ocz * dz;
+    double c = (ocx * ocx + ocy * ocy + ocz * ocz) - r * r;
+    double disc = hb * hb - a * c;
+    if (disc < 0.0) return false;
+    double sq = sqrt(disc);
+    double root = (-hb - sq) / a;
+    if (!(tmin < root && root < tmax)) {
+        root = (-hb + sq) / a;
+        if (!(tmin < root && root < tmax)) return false;
+    }
+    t_out = root;
+    return true;
+}
+
+__device__ __noinline__ void finish64(double ox, double oy, double oz, double dx, double dy, double dz, double t,
+                                      double cx, double cy, double cz, double r, float *n_out, uint8_t *front) {
+    double px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;
+    double wx = (px - cx) / r, wy = (py - cy) / r, wz = (pz - cz) / r;
+    bool f = (dx * wx + dy * wy + dz * wz) < 0.0;
+    double len = sqrt(wx * wx + wy * wy + wz * wz);
+    double nx = wx / len, ny = wy / len, nz = wz / len;
+    if (!f) { nx = -nx; ny = -ny; nz = -nz; }
+    if (n_out) { n_out[0] = (float)nx; n_out[1] = (float)ny; n_out[2] = (float)nz; }
+    if (front) *front = f ? 1 : 0;
+}
+#pragma clang fp contract(fast)
+
+template <bool REFINE>
+__global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const float *__restrict__ org,
+                                                               const float *__restrict__ dir, float tmin,
+                                                               DeviceScene sc, int n_spheres, int32_t *__restrict__ id,
+                                                               float *__restrict__ t, float *__restrict__ normal,
+                                                               uint8_t *__restrict__ front) {
+    __shared__ float4 lds_sph[STREAM_TILE];
+    const int i = blockIdx.x * WG_THREADS + threadIdx.x;
+    const bool live = i < n_rays;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    if (live) {
+        o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+        d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    }
+    float a = dot(d, d), inv_a = 1.0f / a;
+    float best_t = __builtin_inff();
+    int best_id = -1;
+    for (int base = 0; base < n_spheres; base += STREAM_TILE) {
+        int cnt = min(STREAM_TILE, n_spheres - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cnt; k += WG_THREADS) lds_sph[k] = sc.sph_r2[base + k];
+        __syncthreads();
+        if (live) scan_tile(lds_sph, cnt, base, o, d, a, inv_a, tmin, -1, best_t, best_id);
+    }
+    if (!REFINE) {
+        if (!live) return;
+        id[i] = best_id;
+        if (best_id >= 0) {
+            Hit h = finish_hit(o, d, best_t, sc.sph[best_id]);
+            if (t) t[i] = best_t;
+            if (normal) { normal[3 * i] = h.n.x; normal[3 * i + 1] = h.n.y; normal[3 * i + 2] = h.n.z; }
+            if (front) front[i] = h.front ? 1 : 0;
+        } else {
+            if (t) t[i] = 0.f;
+            if (normal) { normal[3 * i] = 0.f; normal[3 * i + 1] = 0.f; normal[3 * i + 2] = 0.f; }
+            if (front) front[i] = 0;
+        }
+        return;
+    }
+    // Refinement: every sphere whose single-precision evaluation cannot rule it out
+    // (discriminant not clearly negative, nearer root not clearly beyond the
+    // single-precision winner) is re-tested in double precision, in index order with
+    // the shrinking interval of hitClosest.  If that finds no hit inside the window
+    // (the single-precision winner was a false positive) the window is dropped and
+    // every sphere with a non-negative-looking discriminant is re-tested.
+    const float EPS = 2e-3f;
+    float t_lim = best_id >= 0 ? best_t * (1.0f + EPS) + 1e-4f : __builtin_inff();
+    double closest = __builtin_inf();
+    int id64 = -1;
+    if (live) {
+        for (int pass = 0; pass < 2; ++pass) {
+            closest = __builtin_inf();
+            id64 = -1;
+            for (int k = 0; k < n_spheres; ++k) {
+                float4 s = sc.sph[k];
+                float ocx = o.x - s.x, ocy = o.y - s.y, ocz = o.z - s.z;
+                float hb = fmaf(ocx, d.x, fmaf(ocy, d.y, ocz * d.z));
+                float r2 = s.w * s.w;
+                float oc2 = fmaf(ocx, ocx, fmaf(ocy, ocy, ocz * ocz));
+                float c = oc2 - r2;
+                float disc = fmaf(hb, hb, -(a * c));
+                float scale = fmaf(hb, hb, a * (oc2 + r2));
+                if (disc < -EPS * scale) continue;
+                float sq = __fsqrt_rn(fmaxf(disc, 0.f) + EPS * scale);
+                float near_root = (-hb - sq) * inv_a; // a lower bound of the nearer root
+                if (near_root > t_lim) continue;
+                double tt;
+                if (hit64(o.x, o.y, o.z, d.x, d.y, d.z, (double)tmin, closest, s.x, s.y, s.z, s.w, tt)) {
+                    closest = tt;
+                    id64 = k;
+                }
+            }
+            if (closest <= (double)t_lim) break; // a verified hit inside the window: nothing outside can beat it
+            if (!(t_lim < __builtin_inff())) break; // the window was already unbounded
+            t_lim = __builtin_inff();
+        }
+        id[i] = id64;
+        if (id64 >= 0) {
+            float4 s = sc.sph[id64];
+            if (t) t[i] = (float)closest;
+            finish64(o.x, o.y, o.z, d.x, d.y, d.z, closest, s.x, s.y, s.z, s.w, normal ? normal + 3 * i : nullptr,
+                     front ? front + i : nullptr);
+        } else {
+            if (t) t[i] = 0.f;
+            if (normal) { normal[3 * i] = 0.f; normal[3 * i + 1] = 0.f; normal[3 * i + 2] = 0.f; }
+            if (front) front[i] = 0;
+        }
+    }
+}
+
+// Batch scatter: the bounce step of the render kernel on explicit inputs.
+__global__ void scatter_kernel(int n, const DMat *__restrict__ mats, const uint32_t *__restrict__ mat,
+                               const float *__restrict__ in_dir, const float *__restrict__ point,
+                               const float *__restrict__ nrm, const uint8_t *__restrict__ front,
+                               const float *__restrict__ u, float *__restrict__ att, float *__restrict__ out_org,
+                               float *__restrict__ out_dir, uint8_t *__restrict__ flag) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DMat &m = mats[mat[i]];
+    float4 at = m.albedo_type, ef = m.emission_fuzz;
+    Hit h;
+    h.p = mk(point[3 * i], point[3 * i + 1], point[3 * i + 2]);
+    h.n = mk(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+    h.front = front[i] != 0;
+    V3 a = mk(0, 0, 0), o = mk(0, 0, 0), d = mk(0, 0, 0);
+    bool ok = scatter(__float_as_uint(at.w), mk(at.x, at.y, at.z), ef.w, m.ior_pad.x,
+                      mk(in_dir[3 * i], in_dir[3 * i + 1], in_dir[3 * i + 2]), h, u[3 * i], u[3 * i + 1], u[3 * i + 2],
+                      a, o, d);
+    flag[i] = ok ? 1 : 0;
+    if (!ok) { a = mk(0, 0, 0); o = mk(0, 0, 0); d = mk(0, 0, 0); }
+    att[3 * i] = a.x; att[3 * i + 1] = a.y; att[3 * i + 2] = a.z;
+    out_org[3 * i] = o.x; out_org[3 * i + 1] = o.y; out_org[3 * i + 2] = o.z;
+    out_dir[3 * i] = d.x; out_dir[3 * i + 1] = d.y; out_dir[3 * i + 2] = d.z;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+struct rt_ctx {
+    int device = 0;
+    std::string err;
+    float4 *d_sph = nullptr;
+    float4 *d_sph_r2 = nullptr;
+    uint32_t *d_mat_id = nullptr;
+    DMat *d_mats = nullptr;
+    int n_spheres = 0;
+    int n_mats = 0;
+    bool have_scene = false;
+    bool have_camera = false;
+    rt_camera cam{};
+};
+
+namespace {
+
+int fail(rt_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                            \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(ctx, RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+void free_scene(rt_ctx *ctx) {
+    if (ctx->d_sph) (void)hipFree(ctx->d_sph);
+    if (ctx->d_sph_r2) (void)hipFree(ctx->d_sph_r2);
+    if (ctx->d_mat_id) (void)hipFree(ctx->d_mat_id);
+    if (ctx->d_mats) (void)hipFree(ctx->d_mats);
+    ctx->d_sph = ctx->d_sph_r2 = nullptr;
+    ctx->d_mat_id = nullptr;
+    ctx->d_mats = nullptr;
+    ctx->have_scene = false;
+}
+
+int check_params(rt_ctx *ctx, const rt_params *p) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!p) return fail(ctx, RT_ERR_INVALID, "params is null");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (!ctx->have_camera) return fail(ctx, RT_ERR_STATE, "no camera set");
+    if (p->width <= 0 || p->height <= 0) return fail(ctx, RT_ERR_INVALID, "width/height must be positive");
+    if ((long long)p->width * (long long)p->height > 0x7fffffffLL)
+        return fail(ctx, RT_ERR_INVALID, "width*height exceeds 2^31-1");
+    if (p->samples_per_pixel <= 0) return fail(ctx, RT_ERR_INVALID, "samples_per_pixel must be positive");
+    if (p->max_depth < 0) return fail(ctx, RT_ERR_INVALID, "max_depth must be non-negative");
+    if (p->sample_offset < 0) return fail(ctx, RT_ERR_INVALID, "sample_offset must be non-negative");
+    if (p->strip_stride <= 0 || p->strip_first < 0 || p->strip_first >= p->strip_stride)
+        return fail(ctx, RT_ERR_INVALID, "need 0 <= strip_first < strip_stride");
+    if ((long long)p->samples_per_pixel * 64LL > 0xffffffffLL)
+        return fail(ctx, RT_ERR_INVALID, "samples_per_pixel too large for one call (max 2^26-1)");
+    return RT_OK;
+}
+
+int local_strips(const rt_params *p) {
+    int strips = (p->height + RT_STRIP_ROWS - 1) / RT_STRIP_ROWS;
+    if (p->strip_first >= strips) return 0;
+    return (strips - p->strip_first + p->strip_stride - 1) / p->strip_stride;
+}
+
+} // namespace
+
+RT_API int rt_version(void) { return 100; }
+
+RT_API void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint32_t out[4]) {
+    rng4(pixel, sample, call, seed, out[0], out[1], out[2], out[3]);
+}
+
+RT_API int rt_output_rows(const rt_params *p) {
+    if (!p || p->strip_stride <= 0) return 0;
+    if (p->strip_stride == 1) return p->height;
+    return local_strips(p) * RT_STRIP_ROWS;
+}
+
+RT_API int rt_create(int device, rt_ctx **out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RT_ERR_HIP;
+    if (device < 0 || device >= count) return RT_ERR_INVALID;
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_HIP;
+    }
+    // allow the render kernels their dynamic LDS budget
+    size_t lds_resident = 3072 + (size_t)RESIDENT_MAX * sizeof(float4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_resident);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_resident);
+    *out = ctx;
+    return RT_OK;
+}
+
+RT_API void rt_destroy(rt_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    free_scene(ctx);
+    delete ctx;
+}
+
+RT_API const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+RT_API int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_spheres, const uint32_t *h_mat_id,
+                           int n_mats, const rt_material *h_mats) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (n_spheres < 0 || n_mats < 0) return fail(ctx, RT_ERR_INVALID, "negative count");
+    if (n_spheres > 0 && (!h_spheres || !h_mat_id || !h_mats || n_mats == 0))
+        return fail(ctx, RT_ERR_INVALID, "null scene array");
+    for (int i = 0; i < n_spheres; ++i)
+        if (h_mat_id[i] >= (uint32_t)n_mats) return fail(ctx, RT_ERR_INVALID, "mat_id out of range");
+    for (int i = 0; i < n_mats; ++i)
+        if (h_mats[i].type > RT_MAT_EMISSIVE) return fail(ctx, RT_ERR_UNSUPPORTED, "unknown material type");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    free_scene(ctx);
+    // keep at least one element allocated so kernels always get valid pointers
+    size_t ns = (size_t)(n_spheres > 0 ? n_spheres : 1), nm = (size_t)(n_mats > 0 ? n_mats : 1);
+    std::vector<float4> sph(ns, make_float4(0, 0, 0, 0)), sph2(ns, make_float4(0, 0, 0, 0));
+    std::vector<uint32_t> mid(ns, 0);
+    std::vector<DMat> mats(nm);
+    for (int i = 0; i < n_spheres; ++i) {
+        const rt_sphere &s = h_spheres[i];
+        sph[i] = make_float4(s.cx, s.cy, s.cz, s.r);
+        sph2[i] = make_float4(s.cx, s.cy, s.cz, s.r * s.r);
+        mid[i] = h_mat_id[i];
+    }
+    for (size_t i = 0; i < nm; ++i) {
+        DMat m;
+        memset(&m, 0, sizeof m);
+        if ((int)i < n_mats) {
+            const rt_material &h = h_mats[i];
+            float tbits;
+            uint32_t ty = h.type;
+            memcpy(&tbits, &ty, 4);
+            m.albedo_type = make_float4(h.albedo[0], h.albedo[1], h.albedo[2], tbits);
+            m.emission_fuzz = make_float4(h.emission[0], h.emission[1], h.emission[2], h.fuzz);
+            m.ior_pad = make_float4(h.ior, 0, 0, 0);
+        }
+        mats[i] = m;
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_sph, ns * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_sph_r2, ns * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_mat_id, ns * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_mats, nm * sizeof(DMat)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_sph, sph.data(), ns * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_sph_r2, sph2.data(), ns * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_mat_id, mid.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_mats, mats.data(), nm * sizeof(DMat), hipMemcpyHostToDevice));
+    ctx->n_spheres = n_spheres;
+    ctx->n_mats = n_mats;
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+RT_API int rt_set_camera(rt_ctx *ctx, const rt_camera *cam) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!cam) return fail(ctx, RT_ERR_INVALID, "camera is null");
+    ctx->cam = *cam;
+    ctx->have_camera = true;
+    return RT_OK;
+}
+
+RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, uint64_t *d_rays,
+                     void *stream) {
+    int rc = check_params(ctx, p);
+    if (rc != RT_OK) return rc;
+    if (!d_rgba) return fail(ctx, RT_ERR_INVALID, "d_rgba is null");
+    if ((p->flags & RT_FLAG_ACCUMULATE) && !d_accum)
+        return fail(ctx, RT_ERR_INVALID, "RT_FLAG_ACCUMULATE needs d_accum");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KParams k;
+    k.width = p->width;
+    k.height = p->height;
+    k.spp = p->samples_per_pixel;
+    k.max_depth = p->max_depth;
+    k.sample_offset = p->sample_offset;
+    k.seed = p->seed;
+    k.flags = p->flags;
+    k.strip_first = p->strip_first;
+    k.strip_stride = p->strip_stride;
+    k.tiles_x = (p->width + WG_TILE_W - 1) / WG_TILE_W;
+    k.n_spheres = ctx->n_spheres;
+    k.inv_w = 1.0f / (float)p->width;
+    k.inv_h = 1.0f / (float)p->height;
+    memcpy(k.cam + 0, ctx->cam.center, 12);
+    memcpy(k.cam + 3, ctx->cam.upper_left, 12);
+    memcpy(k.cam + 6, ctx->cam.right, 12);
+    memcpy(k.cam + 9, ctx->cam.down, 12);
+    DeviceScene sc{ctx->d_sph, ctx->d_sph_r2, ctx->d_mat_id, ctx->d_mats};
+    int nstrips = local_strips(p);
+    if (nstrips == 0) return RT_OK;
+    dim3 grid((unsigned)(nstrips * k.tiles_x)), block(WG_THREADS);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (ctx->n_spheres <= RESIDENT_MAX) {
+        size_t lds = 3072 + (size_t)(ctx->n_spheres > 0 ? ctx->n_spheres : 1) * sizeof(float4);
+        hipLaunchKernelGGL(render_kernel<false>, grid, block, lds, st, k, sc, (uchar4 *)d_rgba, (float4 *)d_accum,
+                           (unsigned long long *)d_rays);
+    } else {
+        size_t lds = 3072 + (size_t)STREAM_TILE * sizeof(float4);
+        hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, st, k, sc, (uchar4 *)d_rgba, (float4 *)d_accum,
+                           (unsigned long long *)d_rays);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+RT_API int rt_render_host(rt_ctx *ctx, const rt_params *p, uint8_t *h_rgba, float *h_accum, uint64_t *h_rays) {
+    int rc = check_params(ctx, p);
+    if (rc != RT_OK) return rc;
+    if (!h_rgba) return fail(ctx, RT_ERR_INVALID, "h_rgba is null");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t npx = (size_t)rt_output_rows(p) * (size_t)p->width;
+    if (npx == 0) {
+        if (h_rays) *h_rays = 0;
+        return RT_OK;
+    }
+    void *d_rgba = nullptr, *d_accum = nullptr;
+    uint64_t *d_rays = nullptr;
+    hipError_t e = hipMalloc(&d_rgba, npx * 4);
+    if (e == hipSuccess && (h_accum || (p->flags & RT_FLAG_ACCUMULATE))) e = hipMalloc(&d_accum, npx * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_rays, 8);
+    if (e == hipSuccess) e = hipMemset(d_rays, 0, 8);
+    if (e == hipSuccess) e = hipMemset(d_rgba, 0, npx * 4);
+    if (e == hipSuccess && d_accum) {
+        if ((p->flags & RT_FLAG_ACCUMULATE) && h_accum)
+            e = hipMemcpy(d_accum, h_accum, npx * 16, hipMemcpyHostToDevice);
+        else
+            e = hipMemset(d_accum, 0, npx * 16);
+    }
+    if (e == hipSuccess) {
+        rc = rt_render(ctx, p, d_rgba, d_accum, d_rays, nullptr);
+        if (rc == RT_OK) e = hipDeviceSynchronize();
+        if (rc == RT_OK && e == hipSuccess) e = hipMemcpy(h_rgba, d_rgba, npx * 4, hipMemcpyDeviceToHost);
+        if (rc == RT_OK && e == hipSuccess && h_accum) e = hipMemcpy(h_accum, d_accum, npx * 16, hipMemcpyDeviceToHost);
+        if (rc == RT_OK && e == hipSuccess && h_rays) e = hipMemcpy(h_rays, d_rays, 8, hipMemcpyDeviceToHost);
+    }
+    if (d_rgba) (void)hipFree(d_rgba);
+    if (d_accum) (void)hipFree(d_accum);
+    if (d_rays) (void)hipFree(d_rays);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("rt_render_host: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+RT_API int rt_first_hit(rt_ctx *ctx, int n_rays, const float *d_org, const float *d_dir, float tmin, uint32_t flags,
+                        int32_t *d_id, float *d_t, float *d_normal, uint8_t *d_front, void *stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (n_rays < 0) return fail(ctx, RT_ERR_INVALID, "negative ray count");
+    if (n_rays == 0) return RT_OK;
+    if (!d_org || !d_dir || !d_id) return fail(ctx, RT_ERR_INVALID, "null ray/id array");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceScene sc{ctx->d_sph, ctx->d_sph_r2, ctx->d_mat_id, ctx->d_mats};
+    dim3 grid((unsigned)((n_rays + WG_THREADS - 1) / WG_THREADS)), block(WG_THREADS);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (flags & RT_FH_REFINE)
+        hipLaunchKernelGGL(first_hit_kernel<true>, grid, block, 0, st, n_rays, d_org, d_dir, tmin, sc, ctx->n_spheres,
+                           d_id, d_t, d_normal, d_front);
+    else
+        hipLaunchKernelGGL(first_hit_kernel<false>, grid, block, 0, st, n_rays, d_org, d_dir, tmin, sc,
+                           ctx->n_spheres, d_id, d_t, d_normal, d_front);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+namespace {
+// small RAII helper for the host-pointer wrappers
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+} // namespace
+
+RT_API int rt_first_hit_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir, float tmin,
+                             uint32_t flags, int32_t *h_id, float *h_t, float *h_normal, uint8_t *h_front) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (n_rays < 0) return fail(ctx, RT_ERR_INVALID, "negative ray count");
+    if (n_rays == 0) return RT_OK;
+    if (!h_org || !h_dir || !h_id) return fail(ctx, RT_ERR_INVALID, "null ray/id array");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t n = (size_t)n_rays;
+    DevBuf org, dir, id, t, nrm, fr;
+    HIP_TRY(ctx, org.alloc(n * 12));
+    HIP_TRY(ctx, dir.alloc(n * 12));
+    HIP_TRY(ctx, id.alloc(n * 4));
+    HIP_TRY(ctx, t.alloc(n * 4));
+    HIP_TRY(ctx, nrm.alloc(n * 12));
+    HIP_TRY(ctx, fr.alloc(n));
+    HIP_TRY(ctx, hipMemcpy(org.p, h_org, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dir.p, h_dir, n * 12, hipMemcpyHostToDevice));
+    int rc = rt_first_hit(ctx, n_rays, (const float *)org.p, (const float *)dir.p, tmin, flags, (int32_t *)id.p,
+                          (float *)t.p, (float *)nrm.p, (uint8_t *)fr.p, nullptr);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(h_id, id.p, n * 4, hipMemcpyDeviceToHost));
+    if (h_t) HIP_TRY(ctx, hipMemcpy(h_t, t.p, n * 4, hipMemcpyDeviceToHost));
+    if (h_normal) HIP_TRY(ctx, hipMemcpy(h_normal, nrm.p, n * 12, hipMemcpyDeviceToHost));
+    if (h_front) HIP_TRY(ctx, hipMemcpy(h_front, fr.p, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+RT_API int rt_scatter_host(rt_ctx *ctx, int n, const uint32_t *h_mat, const float *h_in_dir, const float *h_point,
+                           const float *h_normal, const uint8_t *h_front, const float *h_u, float *h_att,
+                           float *h_out_org, float *h_out_dir, uint8_t *h_scattered_flag) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (n < 0) return fail(ctx, RT_ERR_INVALID, "negative count");
+    if (n == 0) return RT_OK;
+    if (!h_mat || !h_in_dir || !h_point || !h_normal || !h_front || !h_u || !h_att || !h_out_org || !h_out_dir ||
+        !h_scattered_flag)
+        return fail(ctx, RT_ERR_INVALID, "null array");
+    for (int i = 0; i < n; ++i)
+        if (h_mat[i] >= (uint32_t)ctx->n_mats) return fail(ctx, RT_ERR_INVALID, "material index out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t N = (size_t)n;
+    DevBuf mat, ind, pnt, nrm, fr, u, att, oo, od, fl;
+    HIP_TRY(ctx, mat.alloc(N * 4));
+    HIP_TRY(ctx, ind.alloc(N * 12));
+    HIP_TRY(ctx, pnt.alloc(N * 12));
+    HIP_TRY(ctx, nrm.alloc(N * 12));
+    HIP_TRY(ctx, fr.alloc(N));
+    HIP_TRY(ctx, u.alloc(N * 12));
+    HIP_TRY(ctx, att.alloc(N * 12));
+    HIP_TRY(ctx, oo.alloc(N * 12));
+    HIP_TRY(ctx, od.alloc(N * 12));
+    HIP_TRY(ctx, fl.alloc(N));
+    HIP_TRY(ctx, hipMemcpy(mat.p, h_mat, N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ind.p, h_in_dir, N * 12, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(pnt.p, h_point, N * 12, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(nrm.p, h_normal, N * 12, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(fr.p, h_front, N, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(u.p, h_u, N * 12, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, n, ctx->d_mats,
+                       (const uint32_t *)mat.p, (const float *)ind.p, (const float *)pnt.p, (const float *)nrm.p,
+                       (const uint8_t *)fr.p, (const float *)u.p, (float *)att.p, (float *)oo.p, (float *)od.p,
+                       (uint8_t *)fl.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(h_att, att.p, N * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(h_out_org, oo.p, N * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(h_out_dir, od.p, N * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(h_scattered_flag, fl.p, N, hipMemcpyDeviceToHost));
+    return RT_OK;
+}

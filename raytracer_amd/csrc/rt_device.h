@@ -1,0 +1,207 @@
+// rt_device.h — device-side building blocks of the gfx950 path tracer:
+// counter-based RNG, vec3 helpers, the ray/sphere test, the four scatter
+// functions and the tone-map.  Each block names the reference lines it follows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+struct V3 {
+    float x, y, z;
+};
+
+__host__ __device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__host__ __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__host__ __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__host__ __device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__host__ __device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__host__ __device__ __forceinline__ float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+// a + b*s
+__host__ __device__ __forceinline__ V3 madd(V3 a, V3 b, float s) {
+    return mk(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z));
+}
+__device__ __forceinline__ V3 normalized(V3 a) { return a * __frsqrt_rn(dot(a, a)); }
+
+// Device copy of one material: three 16-byte words.
+struct DMat {
+    float4 albedo_type; // albedo rgb, type in the bits of .w
+    float4 emission_fuzz; // emission rgb, fuzz
+    float4 ior_pad;       // ior, unused
+};
+
+// ---- random numbers ------------------------------------------------------
+// pcg4d (Jarzynski & Olano, JCGT 2020) keyed on (pixel, sample, call, seed): one
+// evaluation yields the four words a bounce can consume.  Stands in for the
+// per-thread generator the reference seeds per pixel (src/Camera.cpp:84).
+__host__ __device__ __forceinline__ void rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed,
+                                              uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+    uint32_t x = pixel * 1664525u + 1013904223u;
+    uint32_t y = sample * 1664525u + 1013904223u;
+    uint32_t z = call * 1664525u + 1013904223u;
+    uint32_t w = seed * 1664525u + 1013904223u;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    o0 = x; o1 = y; o2 = z; o3 = w;
+}
+
+// 24-bit uniform in [0,1), exactly representable in float and double.
+__host__ __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+
+// Uniform direction on the unit sphere from two uniforms (the role of
+// IVec3f::randomUnit(), called at inc/RTMaterial.h:72,111).
+// v_sin_f32 / v_cos_f32 take their argument in revolutions, so u1 feeds them directly.
+__device__ __forceinline__ V3 random_unit(float u0, float u1) {
+    float z = fmaf(-2.0f, u0, 1.0f);
+    float r = __fsqrt_rn(fmaxf(fmaf(-z, z, 1.0f), 0.0f));
+    float s = __builtin_amdgcn_sinf(u1);
+    float c = __builtin_amdgcn_cosf(u1);
+    return mk(r * c, r * s, z);
+}
+
+// ---- ray / sphere ----------------------------------------------------------
+// One ray against one sphere, given as (centre, radius^2): the decision of
+// SphereObject::hitDetail up to the root selection (inc/RTObjects.h:135-149)
+// with Interval::surrounds' open interval (inc/RTGeometry.h:79-81).
+// `a` = d.d and inv_a = 1/a are per-ray constants.  Updates (best_t, best_id)
+// when the sphere is hit inside (tmin, best_t).
+//
+// Single-precision care, none of which changes the real-number result:
+//   * c = |oc|^2 - r^2 is accumulated onto -r^2 so the cancellation happens inside
+//     fused multiply-adds rather than after a rounded |oc|^2;
+//   * the two roots (-hb -+ sqrt(disc))/a are formed as q/a and c/q with
+//     q = -hb -+ sqrt(disc) taking the sign that adds magnitudes, so the root
+//     near the origin does not lose its digits to cancellation;
+//   * `self_id` names the sphere whose surface the ray starts on (-1: none).  Its
+//     constant term is exactly zero in real arithmetic but rounding noise of size
+//     ulp(|oc|)*r in floats, so it is skipped here and handled in closed form by
+//     self_hit() below.
+__device__ __forceinline__ void test_sphere(float ox, float oy, float oz, float dx, float dy, float dz, float a,
+                                            float inv_a, float tmin, float4 s, int idx, int self_id,
+                                            float &best_t, int &best_id) {
+    float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+    float hb = fmaf(ocx, dx, fmaf(ocy, dy, ocz * dz));
+    float c = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -s.w)));
+    float disc = fmaf(hb, hb, -(a * c));
+    if (disc >= 0.0f) {
+        float sq = __builtin_amdgcn_sqrtf(disc);
+        float q = hb < 0.0f ? sq - hb : -sq - hb; // |q| = |hb| + sq
+        float r0 = q * inv_a, r1 = c / q;
+        float t_near = hb < 0.0f ? r1 : r0;
+        float t_far = hb < 0.0f ? r0 : r1;
+        float root = (t_near > tmin && t_near < best_t) ? t_near : t_far;
+        if (root > tmin && root < best_t && idx != self_id) {
+            best_t = root;
+            best_id = idx;
+        }
+    }
+}
+
+// The sphere a ray starts on: with the origin exactly on the surface the roots are
+// 0 and -2*hb/a; 0 is outside (tmin, .), so only the second can be a hit.
+__device__ __forceinline__ void self_hit(float ox, float oy, float oz, float dx, float dy, float dz, float inv_a,
+                                         float tmin, float4 sph, int self_id, float &best_t, int &best_id) {
+    float hb = fmaf(ox - sph.x, dx, fmaf(oy - sph.y, dy, (oz - sph.z) * dz));
+    float t = -2.0f * hb * inv_a;
+    if (t > tmin && t < best_t) {
+        best_t = t;
+        best_id = self_id;
+    }
+}
+
+struct Hit {
+    V3 p, n;
+    bool front;
+};
+
+// Hit point, outward normal and face flag for the winning sphere
+// (inc/RTObjects.h:151-155, HitRecord::setFaceNormal inc/RTGeometry.h:58-61).
+// (P-C)/r normalised is sign(r) * (P-C)/|P-C|, so only the sign of r is needed.
+__device__ __forceinline__ Hit finish_hit(V3 o, V3 d, float t, float4 sph) {
+    Hit h;
+    h.p = madd(o, d, t);
+    V3 pc = h.p - mk(sph.x, sph.y, sph.z);
+    float k = __frsqrt_rn(dot(pc, pc));
+    k = sph.w < 0.0f ? -k : k;
+    V3 outward = pc * k;
+    h.front = dot(d, outward) < 0.0f;
+    h.n = h.front ? outward : outward * -1.0f;
+    return h;
+}
+
+// ---- materials -------------------------------------------------------------
+// reflect(), inc/RTGeometry.h:18-20
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return madd(v, n, -2.0f * dot(v, n)); }
+
+// RTDielectric::reflectance (Schlick), inc/RTMaterial.h:193-197
+__device__ __forceinline__ float reflectance(float cosine, float ri) {
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    float m = 1.0f - cosine;
+    float m2 = m * m;
+    return fmaf(1.0f - r0, m2 * m2 * m, r0);
+}
+
+// RTMaterial::scatter for the four kinds (inc/RTMaterial.h:67-80, 105-115,
+// 142-170, 205-207).  Returns false when the path ends (emissive).
+// u0,u1 drive random_unit, u2 is the dielectric's reflect-or-refract draw.
+__device__ __forceinline__ bool scatter(uint32_t type, V3 albedo, float fuzz, float ior, V3 d_in, const Hit &h,
+                                        float u0, float u1, float u2, V3 &att, V3 &o_out, V3 &d_out) {
+    att = albedo;
+    if (type == 0u) { // Lambertian: normal + random unit vector, not normalised
+        V3 dir = h.n + random_unit(u0, u1);
+        if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = h.n;
+        o_out = h.p;
+        d_out = dir;
+        return true;
+    }
+    if (type == 1u) { // Metal: always scatters, even below the surface
+        V3 r = reflect(d_in, h.n);
+        d_out = madd(normalized(r), random_unit(u0, u1), fuzz);
+        o_out = h.p;
+        return true;
+    }
+    if (type == 2u) { // Dielectric
+        float eta = h.front ? (1.0f / ior) : ior;
+        V3 unit = normalized(d_in);
+        float cos_t = fminf(-dot(unit, h.n), 1.0f);
+        float sin_t = __fsqrt_rn(fmaxf(fmaf(-cos_t, cos_t, 1.0f), 0.0f));
+        bool cannot = eta * sin_t > 1.0f;
+        V3 dir;
+        if (cannot || reflectance(cos_t, eta) > u2) {
+            dir = reflect(unit, h.n);
+        } else {
+            // refract(), inc/RTGeometry.h:22-34, including the 1/eta^2 rescale at :28;
+            // the assert at :30 becomes a clamp at zero.
+            V3 perp = (unit + h.n * cos_t) * eta;
+            float k = 1.0f - dot(perp, perp);
+            if (k < 0.0f) {
+                perp = perp * (1.0f / (eta * eta));
+                k = 1.0f - dot(perp, perp);
+            }
+            dir = madd(perp, h.n, -__fsqrt_rn(fmaxf(k, 0.0f)));
+        }
+        // origin nudged along the face normal towards the geometric outside (:165-166)
+        o_out = madd(h.p, h.n, h.front ? 1e-4f : -1e-4f);
+        d_out = normalized(dir);
+        return true;
+    }
+    return false; // Emissive
+}
+
+// sky colour on a miss, src/Camera.cpp:155-156 (direction used un-normalised)
+__device__ __forceinline__ V3 sky(V3 d) {
+    float a = 0.5f * (d.y + 1.0f);
+    float b = 1.0f - a;
+    return mk(fmaf(0.5f, a, b), fmaf(0.7f, a, b), fmaf(1.0f, a, b));
+}
+
+// linearToGamma + clamp + byte conversion, src/Camera.cpp:11-34
+__device__ __forceinline__ uint32_t to_byte(float x) {
+    float g = x > 0.0f ? __fsqrt_rn(x) : 0.0f;
+    g = fminf(fmaxf(g, 0.0f), 0.999f);
+    return (uint32_t)(256.0f * g);
+}
+
+} // namespace rt

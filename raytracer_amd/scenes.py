@@ -1,0 +1,188 @@
+"""Build-defined scenes for the benchmark configurations.
+
+The reference ships no scenes; these are "Ray Tracing in One Weekend" look-alikes
+adapted to the reference camera's conventions (world up = +z unless the view
+direction is within 0.999 of it, fixed 1x1 viewport at focal length 1 —
+reference src/Camera.cpp:206-221, inc/Camera.h:24-26,48).
+
+Every number is rounded to float32 here, so the HIP library and the CPU oracle
+receive bit-identical inputs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .api import CAMERA_DTYPE, MATERIAL_DTYPE, SPHERE_DTYPE, MAT_DIELECTRIC, MAT_EMISSIVE, MAT_LAMBERTIAN, MAT_METAL
+
+
+@dataclass
+class Scene:
+    name: str
+    spheres: np.ndarray  # SPHERE_DTYPE [n]
+    mat_id: np.ndarray  # uint32 [n]
+    mats: np.ndarray  # MATERIAL_DTYPE [m]
+    camera: np.ndarray  # CAMERA_DTYPE [1]
+
+    @property
+    def n_spheres(self) -> int:
+        return len(self.spheres)
+
+
+def make_camera(center=(0.0, 0.0, 0.0), direction=(0.0, 0.0, 1.0)) -> np.ndarray:
+    """Camera::setCenter/setDirection + updateViewPort (reference src/Camera.cpp:206-236)."""
+    c = np.asarray(center, dtype=np.float64)
+    d = np.asarray(direction, dtype=np.float64)
+    d = d / np.sqrt(np.dot(d, d))
+    up = np.array([0.0, 0.0, 1.0])
+    if abs(np.dot(d, up)) > 0.999:
+        up = np.array([0.0, 1.0, 0.0])
+    right = np.cross(d, up)
+    right = right / np.sqrt(np.dot(right, right))
+    down = np.cross(d, right)
+    down = down / np.sqrt(np.dot(down, down))
+    ul = c + d * 1.0 - right * 1.0 * 0.5 - down * 1.0 * 0.5
+    cam = np.zeros(1, dtype=CAMERA_DTYPE)
+    cam["center"][0] = c
+    cam["upper_left"][0] = ul
+    cam["right"][0] = right
+    cam["down"][0] = down
+    return cam
+
+
+class _Builder:
+    def __init__(self):
+        self.sph = []
+        self.mid = []
+        self.mats = []
+
+    def mat(self, type_, albedo=(0, 0, 0), fuzz=0.0, ior=1.0, emission=(0, 0, 0)) -> int:
+        self.mats.append((type_, tuple(albedo), min(float(fuzz), 1.0), float(ior), tuple(emission)))
+        return len(self.mats) - 1
+
+    def lambertian(self, albedo):
+        return self.mat(MAT_LAMBERTIAN, albedo)
+
+    def metal(self, albedo, fuzz):
+        return self.mat(MAT_METAL, albedo, fuzz=fuzz)
+
+    def dielectric(self, tint, ior):
+        return self.mat(MAT_DIELECTRIC, tint, ior=ior)
+
+    def emissive(self, emission):
+        return self.mat(MAT_EMISSIVE, emission=emission)
+
+    def sphere(self, center, radius, mat):
+        self.sph.append((float(center[0]), float(center[1]), float(center[2]), float(radius)))
+        self.mid.append(mat)
+
+    def build(self, name, camera) -> Scene:
+        spheres = np.array(self.sph, dtype=np.float32).reshape(-1, 4).view(SPHERE_DTYPE).reshape(-1)
+        mats = np.zeros(len(self.mats), dtype=MATERIAL_DTYPE)
+        for i, (t, a, f, ior, e) in enumerate(self.mats):
+            mats[i]["type"] = t
+            mats[i]["albedo"] = a
+            mats[i]["fuzz"] = f
+            mats[i]["ior"] = ior
+            mats[i]["emission"] = e
+        return Scene(name, spheres, np.array(self.mid, dtype=np.uint32), mats, camera)
+
+
+def small_scene(bubble: bool = False, light: bool = False) -> Scene:
+    """Ground + diffuse / metal / glass spheres in front of the default camera
+    (centre 0, direction +z, so world-up falls back to +y)."""
+    b = _Builder()
+    ground = b.lambertian((0.8, 0.8, 0.0))
+    center = b.lambertian((0.1, 0.2, 0.5))
+    left = b.metal((0.8, 0.6, 0.2), 0.3)
+    right = b.dielectric((1.0, 1.0, 1.0), 1.5)
+    b.sphere((0.0, -100.5, 3.0), 100.0, ground)
+    b.sphere((0.0, 0.0, 3.0), 0.5, center)
+    b.sphere((-1.0, 0.0, 3.0), 0.5, left)
+    b.sphere((1.0, 0.0, 3.0), 0.5, right)
+    if bubble:  # hollow glass: negative radius flips the normal (reference inc/RTObjects.h:154)
+        b.sphere((1.0, 0.0, 3.0), -0.4, right)
+    if light:
+        b.sphere((0.0, 1.5, 3.0), 0.4, b.emissive((4.0, 4.0, 4.0)))
+    return b.build("small", make_camera((0, 0, 0), (0, 0, 1)))
+
+
+class _Lcg:
+    """Tiny deterministic generator for scene layout (independent of the render RNG)."""
+
+    def __init__(self, seed):
+        self.s = seed & 0xFFFFFFFFFFFFFFFF
+
+    def u(self) -> float:
+        self.s = (self.s * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return ((self.s >> 40) & 0xFFFFFF) / float(1 << 24)
+
+    def rng(self, lo, hi) -> float:
+        return lo + (hi - lo) * self.u()
+
+
+def random_spheres_scene(seed: int = 12345) -> Scene:
+    """The RTOW "final scene" turned z-up: RTOW (x, y, z) -> (x, -z, y)."""
+    g = _Lcg(seed)
+    b = _Builder()
+    b.sphere((0.0, 0.0, -1000.0), 1000.0, b.lambertian((0.5, 0.5, 0.5)))
+    for a in range(-11, 11):
+        for bb in range(-11, 11):
+            choose = g.u()
+            cx = a + 0.9 * g.u()
+            cy = -(bb + 0.9 * g.u())
+            cz = 0.2
+            if np.sqrt((cx - 4.0) ** 2 + cy ** 2 + (cz - 0.2) ** 2) <= 0.9:
+                continue
+            if choose < 0.8:
+                alb = (g.u() * g.u(), g.u() * g.u(), g.u() * g.u())
+                m = b.lambertian(alb)
+            elif choose < 0.95:
+                alb = (g.rng(0.5, 1), g.rng(0.5, 1), g.rng(0.5, 1))
+                m = b.metal(alb, g.rng(0, 0.5))
+            else:
+                m = b.dielectric((1.0, 1.0, 1.0), 1.5)
+            b.sphere((cx, cy, cz), 0.2, m)
+    b.sphere((0.0, 0.0, 1.0), 1.0, b.dielectric((1.0, 1.0, 1.0), 1.5))
+    b.sphere((-4.0, 0.0, 1.0), 1.0, b.lambertian((0.4, 0.2, 0.1)))
+    b.sphere((4.0, 0.0, 1.0), 1.0, b.metal((0.7, 0.6, 0.5), 0.0))
+    return b.build("random_spheres", make_camera((13.0, -3.0, 2.0), (-13.0, 3.0, -2.0)))
+
+
+def grid_scene(nx: int = 100, ny: int = 100, seed: int = 777) -> Scene:
+    """nx*ny spheres on a unit-pitch grid (+ ground): 70 % glass, 15 % metal, 15 % diffuse."""
+    g = _Lcg(seed)
+    b = _Builder()
+    b.sphere((0.0, 0.0, -1000.0), 1000.0, b.lambertian((0.5, 0.5, 0.5)))
+    for j in range(ny):
+        for i in range(nx):
+            cx = (i - nx / 2 + 0.5) + g.rng(-0.05, 0.05)
+            cy = (j - ny / 2 + 0.5) + g.rng(-0.05, 0.05)
+            choose = g.u()
+            if choose < 0.70:
+                m = b.dielectric((g.rng(0.8, 1), g.rng(0.8, 1), g.rng(0.8, 1)), 1.5)
+            elif choose < 0.85:
+                m = b.metal((g.rng(0.5, 1), g.rng(0.5, 1), g.rng(0.5, 1)), g.rng(0, 0.3))
+            else:
+                m = b.lambertian((g.u() * g.u(), g.u() * g.u(), g.u() * g.u()))
+            b.sphere((cx, cy, 0.4), 0.4, m)
+    ext = 0.5 * max(nx, ny)
+    return b.build(f"grid{nx}x{ny}", make_camera((0.9 * ext, -1.1 * ext, 0.6 * ext), (-0.9, 1.1, -0.6)))
+
+
+def by_name(name: str) -> Scene:
+    if name == "small":
+        return small_scene()
+    if name == "small_bubble":
+        return small_scene(bubble=True)
+    if name == "small_light":
+        return small_scene(light=True)
+    if name == "random_spheres":
+        return random_spheres_scene()
+    if name == "grid10k":
+        return grid_scene(100, 100)
+    if name.startswith("grid"):
+        n = int(name[4:])
+        return grid_scene(n, n)
+    raise KeyError(name)

@@ -1,0 +1,289 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Tolerances (north star): first-hit object id bit-exact, t and normal within 1e-5
+relative; converged images within a PSNR / mean-bias bound calibrated against the
+oracle's own seed-to-seed noise floor.
+"""
+import numpy as np
+import pytest
+
+from raytracer_amd import RenderParams, RtError, scenes
+from raytracer_amd.api import output_rows
+
+pytestmark = pytest.mark.gpu
+
+TMIN = float(np.float32(0.001))
+
+
+def psnr(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = np.mean(d * d)
+    return 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+# --------------------------------------------------------------------------
+# first hit: SceneManager::hitClosest (reference src/RayTracer.cpp:68-82)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("scene_name,W,H", [("small_bubble", 400, 225), ("random_spheres", 400, 225),
+                                             ("grid24", 160, 90)])
+@pytest.mark.parametrize("jitter", [False, True])
+def test_first_hit_refined_is_exact(renderer, oracle64, scene_name, W, H, jitter):
+    scene = scenes.by_name(scene_name)
+    renderer.set_scene(scene)
+    org, dirs = oracle64.primary_rays(scene.camera, W, H, seed=3, smp=1, jitter=jitter)
+    ids, t, nrm, front = renderer.first_hit(org, dirs, tmin=TMIN, refine=True)
+    oid, ot, onrm, ofront, _ = oracle64.first_hit(scene, org, dirs, tmin=TMIN)
+    assert np.array_equal(ids, oid)
+    hit = oid >= 0
+    assert hit.sum() > 0.3 * len(oid)
+    assert np.array_equal(front[hit], ofront[hit])
+    assert np.max(np.abs(t[hit] - ot[hit]) / np.abs(ot[hit])) <= 1e-5
+    assert np.max(np.linalg.norm(nrm[hit] - onrm[hit], axis=1)) <= 1e-5
+
+
+@pytest.mark.parametrize("scene_name,W,H", [("small_bubble", 400, 225), ("random_spheres", 400, 225)])
+def test_first_hit_fp32_matches_except_ambiguous(renderer, oracle64, scene_name, W, H):
+    """The plain single-precision scan (what the render kernel runs) may differ from the
+    double-precision oracle only on rays whose decision is numerically marginal."""
+    scene = scenes.by_name(scene_name)
+    renderer.set_scene(scene)
+    org, dirs = oracle64.primary_rays(scene.camera, W, H, seed=5, smp=0, jitter=True)
+    ids, t, nrm, front = renderer.first_hit(org, dirs, tmin=TMIN, refine=False)
+    oid, ot, onrm, ofront, margin = oracle64.first_hit(scene, org, dirs, tmin=TMIN, want_margin=True)
+    bad = ids != oid
+    assert bad.mean() < 2e-3
+    assert np.all(margin[bad] < 1e-5), f"unambiguous rays disagree: margins {margin[bad]}"
+    ok = (~bad) & (oid >= 0)
+    assert np.array_equal(front[ok], ofront[ok])
+    # single precision: the error of t grows like eps / sqrt(margin) towards grazing incidence,
+    # and the normal's like (t / r) times that; the 1e-5 bar is met by the refined path above.
+    rel_t = np.abs(t[ok] - ot[ok]) / np.abs(ot[ok])
+    clear = margin[ok] >= 1e-3
+    assert np.max(rel_t[clear]) <= 5e-5
+    assert np.median(rel_t) <= 2e-6 and np.max(rel_t) <= 1e-3
+    n_err = np.linalg.norm(nrm[ok] - onrm[ok], axis=1)
+    assert np.median(n_err) <= 1e-5 and np.max(n_err[clear]) <= 2e-3
+
+
+def test_first_hit_secondary_rays(renderer, oracle64):
+    """Un-normalised directions and origins on surfaces (what bounced rays look like)."""
+    scene = scenes.random_spheres_scene()
+    renderer.set_scene(scene)
+    rng = np.random.default_rng(7)
+    n = 20000
+    k = rng.integers(1, scene.n_spheres, n)
+    c = np.stack([scene.spheres["cx"][k], scene.spheres["cy"][k], scene.spheres["cz"][k]], 1).astype(np.float64)
+    r = scene.spheres["r"][k].astype(np.float64)
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    org = (c + nrm * r[:, None]).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dirs = (nrm + d).astype(np.float32)  # Lambertian-style, length in (0, 2)
+    ids, t, gn, front = renderer.first_hit(org, dirs, tmin=TMIN, refine=True)
+    oid, ot, onrm, ofront, _ = oracle64.first_hit(scene, org, dirs, tmin=TMIN)
+    assert np.array_equal(ids, oid)
+    hit = oid >= 0
+    assert np.max(np.abs(t[hit] - ot[hit]) / np.abs(ot[hit])) <= 1e-5
+
+
+def test_first_hit_edge_cases(renderer, oracle64):
+    b = scenes._Builder()
+    m = b.lambertian((0.5, 0.5, 0.5))
+    b.sphere((0, 0, 3), 0.5, m)      # 0
+    b.sphere((0, 0, 3), 0.5, m)      # 1: exact duplicate -> lowest index wins ties
+    b.sphere((0, 2, 3), -0.5, m)     # 2: negative radius
+    b.sphere((5, 0, 0), 1.0, m)      # 3
+    scene = b.build("edge", scenes.make_camera())
+    renderer.set_scene(scene)
+    org = np.array([[0, 0, 0], [0, 2, 0], [0, 0, 3], [0, 0, 0], [3.5, 0, 0], [0, 0.5, 0], [0, 0, 0]], np.float32)
+    dirs = np.array([[0, 0, 1], [0, 0, 2], [0, 0, 1], [0, 1, 0], [1, 0, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    for refine in (False, True):
+        ids, t, nrm, front = renderer.first_hit(org, dirs, tmin=TMIN, refine=refine)
+        oid, ot, onrm, ofront, _ = oracle64.first_hit(scene, org, dirs, tmin=TMIN)
+        assert list(ids) == list(oid) == [0, 2, 0, -1, 3, 0, -1]
+        hit = oid >= 0
+        assert np.allclose(t[hit], ot[hit], rtol=1e-6)
+        assert np.allclose(nrm[hit], onrm[hit], atol=1e-6)
+        assert list(front[hit]) == list(ofront[hit])
+    # zero rays is a no-op
+    ids, *_ = renderer.first_hit(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert len(ids) == 0
+
+
+# --------------------------------------------------------------------------
+# scatter: RTMaterial::scatter (reference inc/RTMaterial.h)
+# --------------------------------------------------------------------------
+def test_scatter_matches_oracle(renderer, oracle64):
+    scene = scenes.small_scene(light=True)
+    renderer.set_scene(scene)
+    rng = np.random.default_rng(11)
+    n = 4096
+    mat = rng.integers(0, len(scene.mats), n).astype(np.uint32)
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    d = rng.normal(size=(n, 3)) * rng.uniform(0.3, 2.0, size=(n, 1))
+    flip = np.sum(d * nrm, axis=1) > 0  # the face normal always opposes the ray
+    d[flip] *= -1
+    pnt = rng.uniform(-3, 3, size=(n, 3))
+    front = rng.integers(0, 2, n).astype(np.uint8)
+    u = rng.integers(0, 1 << 24, size=(n, 3)) / float(1 << 24)
+    f32 = lambda a: a.astype(np.float32)
+    att, oo, od, flag = renderer.scatter(mat, f32(d), f32(pnt), f32(nrm), front, f32(u))
+    ratt, roo, rod, rflag = oracle64.scatter(scene.mats, mat, f32(d), f32(pnt), f32(nrm), front, f32(u))
+    assert np.array_equal(flag, rflag)
+    types = scene.mats["type"][mat]
+    assert set(types) == {0, 1, 2, 3}
+    s = rflag == 1
+    assert np.allclose(att[s], ratt[s], atol=1e-7)
+    assert np.allclose(oo[s], roo[s], atol=2e-6)
+    # reflect/refract decisions must agree except within rounding of the Schlick threshold
+    err = np.linalg.norm(od[s] - rod[s], axis=1)
+    assert np.mean(err > 2e-5) < 2e-3, f"{np.sum(err > 2e-5)} of {s.sum()} scattered directions differ"
+    assert oracle64.refract_clamped() == 0
+
+
+# --------------------------------------------------------------------------
+# render: Camera::render (reference src/Camera.cpp:56-157)
+# --------------------------------------------------------------------------
+def test_render_depth1_is_deterministic_sky(renderer, oracle64):
+    """max_depth 1: a hit returns emission only, a miss the sky gradient — no noise beyond pixel jitter,
+    so fp32 and fp64 sums agree to rounding."""
+    scene = scenes.small_scene(light=True)
+    renderer.set_scene(scene)
+    p = RenderParams(200, 113, samples_per_pixel=4, max_depth=1, seed=9)
+    rgba, accum, rays = renderer.render_host(p, want_accum=True)
+    orgba, oacc, orays = oracle64.render(scene, 200, 113, 4, 1, seed=9)
+    assert rays == orays == 200 * 113 * 4
+    assert np.all(accum[:, :, 3] == 4)
+    # silhouette pixels may flip hit/miss in fp32; everything else matches to rounding
+    d = np.abs(accum[:, :, :3] - oacc).max(axis=2)
+    assert np.mean(d > 1e-4) < 2e-3
+    assert np.mean(rgba[:, :, :3] != orgba[:, :, :3]) < 5e-3
+    assert np.all(rgba[:, :, 3] == 255)
+
+
+@pytest.mark.parametrize("scene_name,W,H,spp,depth", [("small", 160, 90, 256, 10), ("small_light", 160, 90, 256, 50),
+                                                       ("random_spheres", 160, 90, 128, 50)])
+def test_render_converged_parity(renderer, oracle64, scene_name, W, H, spp, depth):
+    scene = scenes.by_name(scene_name)
+    renderer.set_scene(scene)
+    p = RenderParams(W, H, samples_per_pixel=spp, max_depth=depth, seed=21)
+    rgba, accum, rays = renderer.render_host(p, want_accum=True)
+    ra, acc_a, rays_a = oracle64.render(scene, W, H, spp, depth, seed=21)
+    rb, acc_b, rays_b = oracle64.render(scene, W, H, spp, depth, seed=22)
+    floor = psnr(ra[:, :, :3], rb[:, :, :3])  # two independent CPU renders
+    got = psnr(rgba[:, :, :3], ra[:, :, :3])
+    print(f"{scene_name}: PSNR(gpu,cpu)={got:.2f} dB, CPU seed-to-seed floor={floor:.2f} dB")
+    # same seed => same random numbers => correlated noise: must be at least as close as two seeds are
+    assert got >= floor - 0.5
+    bias = (rgba[:, :, :3].astype(np.float64) - ra[:, :, :3]).mean(axis=(0, 1))
+    assert np.max(np.abs(bias)) <= 0.25, f"mean bias {bias} (8-bit units)"
+    lin = accum[:, :, :3].astype(np.float64).mean(axis=(0, 1)) / spp
+    lin_ref = acc_a.mean(axis=(0, 1)) / spp
+    assert np.allclose(lin, lin_ref, rtol=4e-3)
+    assert abs(rays - rays_a) <= 0.004 * rays_a
+    assert oracle64.refract_clamped() == 0
+
+
+def test_render_is_reproducible_and_partition_invariant(renderer):
+    scene = scenes.random_spheres_scene()
+    renderer.set_scene(scene)
+    W, H = 203, 77  # not multiples of the 32x8 tile
+    p = RenderParams(W, H, samples_per_pixel=16, max_depth=20, seed=5)
+    a, acc_a, rays_a = renderer.render_host(p, want_accum=True)
+    b, acc_b, rays_b = renderer.render_host(p, want_accum=True)
+    assert np.array_equal(a, b) and np.array_equal(acc_a, acc_b) and rays_a == rays_b
+    for world in (2, 3, 8):
+        img = np.zeros_like(a)
+        total = 0
+        for rank in range(world):
+            q = RenderParams(W, H, samples_per_pixel=16, max_depth=20, seed=5, strip_first=rank, strip_stride=world)
+            part, _, rays = renderer.render_host(q)
+            total += rays
+            rows = output_rows(q)
+            assert part.shape[0] == rows
+            for k in range(rows // 8):
+                y0 = (rank + k * world) * 8
+                h = min(8, H - y0)
+                if h > 0:
+                    img[y0:y0 + h] = part[k * 8:k * 8 + h]
+        assert np.array_equal(img, a), f"partition over {world} differs from the single render"
+        assert total == rays_a
+
+
+def test_render_progressive_accumulation(renderer):
+    scene = scenes.small_scene()
+    renderer.set_scene(scene)
+    W, H = 64, 40
+    full, acc_full, _ = renderer.render_host(RenderParams(W, H, 32, 10, seed=3), want_accum=True)
+    p1 = RenderParams(W, H, 16, 10, seed=3)
+    _, acc1, _ = renderer.render_host(p1, want_accum=True)
+    p2 = RenderParams(W, H, 16, 10, seed=3, sample_offset=16, flags=1)
+    img2, acc2, _ = renderer.render_host(p2, accum_in=acc1)
+    assert np.all(acc2[:, :, 3] == 32)
+    assert np.allclose(acc2, acc_full, rtol=2e-6, atol=1e-5)
+    assert np.mean(img2 != full) < 1e-3
+
+
+def test_render_edge_cases(renderer, oracle64):
+    # empty scene: every ray misses, image is the sky gradient
+    b = scenes._Builder()
+    scene = b.build("empty", scenes.make_camera())
+    renderer.upload_scene(scene.spheres, scene.mat_id, scene.mats)
+    renderer.set_camera(scene.camera)
+    rgba, acc, rays = renderer.render_host(RenderParams(33, 9, 2, 5, seed=1), want_accum=True)
+    assert rays == 33 * 9 * 2
+    orgba, oacc, _ = oracle64.render(scene, 33, 9, 2, 5, seed=1)
+    assert np.allclose(acc[:, :, :3], oacc, atol=1e-5)
+    assert np.array_equal(rgba, orgba)
+    # max_depth 0: getRayColor returns black at once (reference src/Camera.cpp:138)
+    small = scenes.small_scene()
+    renderer.set_scene(small)
+    rgba, acc, rays = renderer.render_host(RenderParams(16, 8, 3, 0), want_accum=True)
+    assert rays == 0 and not rgba[:, :, :3].any() and np.all(rgba[:, :, 3] == 255)
+    # 1x1 image
+    rgba, _, rays = renderer.render_host(RenderParams(1, 1, 8, 10))
+    assert rgba.shape == (1, 1, 4) and rays >= 8
+
+
+def test_error_behaviour(renderer):
+    from raytracer_amd import Renderer
+
+    fresh = Renderer(0)
+    with pytest.raises(RtError, match="no scene"):
+        fresh.render_host(RenderParams(8, 8, 1, 1))
+    small = scenes.small_scene()
+    fresh.upload_scene(small.spheres, small.mat_id, small.mats)
+    with pytest.raises(RtError, match="no camera"):
+        fresh.render_host(RenderParams(8, 8, 1, 1))
+    fresh.set_camera(small.camera)
+    for bad in (RenderParams(0, 8, 1, 1), RenderParams(8, 8, 0, 1), RenderParams(8, 8, 1, -1),
+                RenderParams(8, 8, 1, 1, strip_first=2, strip_stride=2)):
+        with pytest.raises(RtError):
+            fresh.render_host(bad)
+    with pytest.raises(RtError, match="out of range"):
+        fresh.upload_scene(small.spheres, small.mat_id + 100, small.mats)
+    mats = small.mats.copy()
+    mats["type"][0] = 9
+    with pytest.raises(RtError, match="unknown material"):
+        fresh.upload_scene(small.spheres, small.mat_id, mats)
+    fresh.close()
+
+
+def test_streamed_scene_matches_oracle(renderer, oracle64):
+    """More spheres than stay resident in LDS: the sphere list is streamed through LDS in tiles."""
+    scene = scenes.grid_scene(72, 72)  # 5185 spheres
+    assert scene.n_spheres > 4096
+    renderer.set_scene(scene)
+    W, H = 96, 54
+    org, dirs = oracle64.primary_rays(scene.camera, W, H, seed=1, smp=0, jitter=True)
+    ids, t, nrm, front = renderer.first_hit(org, dirs, tmin=TMIN, refine=True)
+    oid, ot, *_ = oracle64.first_hit(scene, org, dirs, tmin=TMIN)
+    assert np.array_equal(ids, oid)
+    p = RenderParams(W, H, samples_per_pixel=32, max_depth=12, seed=2)
+    rgba, accum, rays = renderer.render_host(p, want_accum=True)
+    ra, acc_a, rays_a = oracle64.render(scene, W, H, 32, 12, seed=2)
+    rb, _, _ = oracle64.render(scene, W, H, 32, 12, seed=3)
+    assert psnr(rgba[:, :, :3], ra[:, :, :3]) >= psnr(ra[:, :, :3], rb[:, :, :3]) - 0.5
+    assert abs(rays - rays_a) <= 0.01 * rays_a
