@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <new>
@@ -36,7 +37,8 @@ constexpr int WAVE_TILE = 8;                 // a wave owns WAVE_TILE x WAVE_TIL
 constexpr int WG_TILE_W = WAVE_TILE * WAVES_PER_WG; // 32
 constexpr int WG_TILE_H = WAVE_TILE;         // 8 == RT_STRIP_ROWS
 constexpr int RESIDENT_MAX = 4096;           // spheres kept resident in LDS (64 KiB)
-constexpr int STREAM_TILE = 2048;            // spheres per streamed LDS tile (32 KiB)
+constexpr int STREAM_QUADS = 512;            // quads (4 spheres, 64 B) per streamed LDS tile (32 KiB)
+constexpr size_t ACC_BYTES = WAVES_PER_WG * 64 * 3 * sizeof(float); // LDS accumulators
 constexpr float TMIN = 0.001f;               // CLOSEST_HIT_MIN_T, src/Camera.cpp:10
 
 static_assert(WG_TILE_H == RT_STRIP_ROWS, "strip height must equal the workgroup tile height");
@@ -47,32 +49,49 @@ struct KParams {
     uint32_t seed, flags;
     int strip_first, strip_stride;
     int tiles_x;     // workgroup tiles per strip
-    int n_spheres;
+    int n_quads;     // sphere quads to scan (padding included)
     float inv_w, inv_h;
     float cam[12];   // center, upper_left, right, down
 };
 
 struct DeviceScene {
     const float4 *sph;    // cx, cy, cz, r
-    const float4 *sph_r2; // cx, cy, cz, r*r  (what the scan loop reads)
+    const float4 *pairs;  // pair-interleaved (centre, r^2) words, see rt_device.h; padded with
+                          // never-hit spheres to a multiple of 4 plus one spare quad
     const uint32_t *mat_id;
     const DMat *mats;
 };
 
-// Scan spheres [0, cnt) of an LDS tile for one ray.
-__device__ __forceinline__ void scan_tile(const float4 *lds, int cnt, int base, V3 o, V3 d, float a, float inv_a,
-                                          float tmin, int self_id, float &best_t, int &best_id) {
-    int i = 0;
-#pragma unroll 1
-    for (; i + 4 <= cnt; i += 4) {
-        float4 s0 = lds[i], s1 = lds[i + 1], s2 = lds[i + 2], s3 = lds[i + 3];
-        test_sphere(o.x, o.y, o.z, d.x, d.y, d.z, a, inv_a, tmin, s0, base + i, self_id, best_t, best_id);
-        test_sphere(o.x, o.y, o.z, d.x, d.y, d.z, a, inv_a, tmin, s1, base + i + 1, self_id, best_t, best_id);
-        test_sphere(o.x, o.y, o.z, d.x, d.y, d.z, a, inv_a, tmin, s2, base + i + 2, self_id, best_t, best_id);
-        test_sphere(o.x, o.y, o.z, d.x, d.y, d.z, a, inv_a, tmin, s3, base + i + 3, self_id, best_t, best_id);
+// Where the scan loop takes the sphere words from.
+enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2 };
+
+// Scan `nquads` groups of four spheres held in LDS (every lane reads the same address:
+// a broadcast read) for one ray.
+__device__ __forceinline__ void scan_lds(const float4 *lds, int nquads, int base, const RayK &r, float tmin,
+                                         int self_id, float &best_t, int &best_id) {
+#pragma unroll 2
+    for (int q = 0; q < nquads; ++q) {
+        float4 A0 = lds[4 * q], B0 = lds[4 * q + 1], A1 = lds[4 * q + 2], B1 = lds[4 * q + 3];
+        test_quad(r, A0, B0, A1, B1, tmin, base + 4 * q, self_id, best_t, best_id);
     }
-    for (; i < cnt; ++i)
-        test_sphere(o.x, o.y, o.z, d.x, d.y, d.z, a, inv_a, tmin, lds[i], base + i, self_id, best_t, best_id);
+}
+
+// Same scan with the sphere words fetched by wave-uniform loads straight from
+// global memory (scalar loads into SGPRs, served by the scalar cache): the words
+// become scalar operands of the packed instructions and no LDS read is issued.
+// The next quad is requested before the current one is tested.
+__device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, int nquads, const RayK &r, float tmin,
+                                            int self_id, float &best_t, int &best_id) {
+    float4 A0 = g[0], B0 = g[1], A1 = g[2], B1 = g[3];
+#pragma unroll 1
+    for (int q = 0; q < nquads; q += 2) {
+        const float4 *n1 = g + 4 * (q + 1); // the spare quad makes q + 1 and q + 2 always readable
+        float4 C0 = n1[0], D0 = n1[1], C1 = n1[2], D1 = n1[3];
+        test_quad(r, A0, B0, A1, B1, tmin, 4 * q, self_id, best_t, best_id);
+        const float4 *n2 = g + 4 * (q + 2);
+        A0 = n2[0]; B0 = n2[1]; A1 = n2[2]; B1 = n2[3];
+        if (q + 1 < nquads) test_quad(r, C0, D0, C1, D1, tmin, 4 * (q + 1), self_id, best_t, best_id);
+    }
 }
 
 // Camera::genRay, src/Camera.cpp:124-135: jittered point on the 1x1 viewport.
@@ -92,7 +111,8 @@ __device__ __forceinline__ void gen_ray(const KParams &p, int px, int py, float 
 struct Path {
     V3 o, d;
     V3 T, L;      // throughput, radiance so far
-    float a, inv_a;
+    V3 dh;        // d / |d|
+    float len, inv_len; // |d| and its reciprocal
     int pix;      // pixel index inside the wave tile, -1 = lane has no work
     uint32_t gpix; // global pixel id (RNG key)
     uint32_t sample;
@@ -101,12 +121,21 @@ struct Path {
     int self_id;  // sphere whose surface the ray starts on exactly (diffuse / metal bounce), else -1
 };
 
-template <bool STREAMED>
+// Per-ray setup of the scan: unit direction, its length, and the packed operands.
+__device__ __forceinline__ void set_dir(Path &pt, V3 d) {
+    pt.d = d;
+    float a = dot(d, d);
+    pt.inv_len = __frsqrt_rn(a);
+    pt.len = a * pt.inv_len;
+    pt.dh = d * pt.inv_len;
+}
+
+template <int SRC>
 __global__ __launch_bounds__(WG_THREADS) void render_kernel(KParams p, DeviceScene sc, uchar4 *__restrict__ rgba,
                                                             float4 *__restrict__ accum,
                                                             unsigned long long *__restrict__ rays_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [0, 3 KiB): per-wave accumulators, 4 waves x 64 pixels x 3 floats; then the sphere tile.
+    // [0, 3 KiB): per-wave accumulators, 4 waves x 64 pixels x 3 floats; then the sphere words.
     float *acc_all = reinterpret_cast<float *>(smem);
     float4 *lds_sph = reinterpret_cast<float4 *>(smem + WAVES_PER_WG * 64 * 3 * sizeof(float));
 
@@ -129,16 +158,16 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KParams p, DeviceSce
     acc[lane + 64] = 0.f;
     acc[lane + 128] = 0.f;
 
-    const int n = p.n_spheres;
-    if (!STREAMED) {
-        for (int i = threadIdx.x; i < n; i += WG_THREADS) lds_sph[i] = sc.sph_r2[i];
+    const int nquads = p.n_quads; // groups of four spheres, padding included
+    if (SRC == SRC_LDS_RESIDENT) {
+        for (int i = threadIdx.x; i < 4 * nquads; i += WG_THREADS) lds_sph[i] = sc.pairs[i];
     }
     __syncthreads();
 
     Path pt;
     pt.pix = -1;
-    pt.o = pt.d = pt.T = pt.L = mk(0, 0, 0);
-    pt.a = pt.inv_a = 1.f;
+    pt.o = pt.d = pt.dh = pt.T = pt.L = mk(0, 0, 0);
+    pt.len = pt.inv_len = 1.f;
     pt.gpix = pt.sample = pt.call = 0;
     pt.depth = 0;
     pt.self_id = -1;
@@ -165,60 +194,61 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KParams p, DeviceSce
                         pt.sample = smp + (uint32_t)p.sample_offset;
                         uint32_t w0, w1, w2, w3;
                         rng4(pt.gpix, pt.sample, 0u, p.seed, w0, w1, w2, w3);
-                        gen_ray(p, px, py, u01(w0), u01(w1), pt.o, pt.d);
-                        pt.a = dot(pt.d, pt.d);
-                        pt.inv_a = 1.0f / pt.a;
+                        V3 d;
+                        gen_ray(p, px, py, u01(w0), u01(w1), pt.o, d);
+                        set_dir(pt, d);
                         pt.T = mk(1, 1, 1);
                         pt.L = mk(0, 0, 0);
                         pt.call = 1;
                         pt.depth = p.max_depth;
                         pt.self_id = -1;
-                        need_work = false;
                     } else {
                         pt.pix = -1;
-                        need_work = false;
                     }
+                    need_work = false;
                 }
             }
         }
         const bool active = pt.pix >= 0 && pt.depth > 0;
-        // a path with depth 0 left (max_depth == 0) contributes black and ends at once
+        // a path with no depth left (max_depth == 0) contributes black and ends at once
         bool finished = pt.pix >= 0 && pt.depth <= 0;
 
-        if (STREAMED) {
+        if (SRC == SRC_LDS_STREAMED) {
             if (!__syncthreads_or(active || finished)) break;
         } else {
             if (!__ballot(active || finished)) break;
         }
 
         // ---- closest hit over all spheres (SceneManager::hitClosest, src/RayTracer.cpp:77-82) ----
-        float best_t = __builtin_inff();
+        float best_t = __builtin_inff(); // in units of |d|
         int best_id = -1;
-        if (STREAMED) {
-            for (int base = 0; base < n; base += STREAM_TILE) {
-                int cnt = min(STREAM_TILE, n - base);
+        const float tmin = TMIN * pt.len;
+        const RayK rk = make_rayk(pt.o, pt.dh);
+        if (SRC == SRC_LDS_STREAMED) {
+            for (int base = 0; base < nquads; base += STREAM_QUADS) {
+                int cnt = min(STREAM_QUADS, nquads - base);
                 __syncthreads();
-                for (int i = threadIdx.x; i < cnt; i += WG_THREADS) lds_sph[i] = sc.sph_r2[base + i];
+                for (int i = threadIdx.x; i < 4 * cnt; i += WG_THREADS) lds_sph[i] = sc.pairs[4 * base + i];
                 __syncthreads();
-                if (active) scan_tile(lds_sph, cnt, base, pt.o, pt.d, pt.a, pt.inv_a, TMIN, pt.self_id, best_t, best_id);
+                if (active) scan_lds(lds_sph, cnt, 4 * base, rk, tmin, pt.self_id, best_t, best_id);
             }
+        } else if (SRC == SRC_LDS_RESIDENT) {
+            if (active) scan_lds(lds_sph, nquads, 0, rk, tmin, pt.self_id, best_t, best_id);
         } else {
-            if (active) scan_tile(lds_sph, n, 0, pt.o, pt.d, pt.a, pt.inv_a, TMIN, pt.self_id, best_t, best_id);
+            if (active) scan_scalar(sc.pairs, nquads, rk, tmin, pt.self_id, best_t, best_id);
         }
 
         // ---- shade + bounce (Camera::getRayColor, src/Camera.cpp:137-157) ----
         if (active) {
             my_rays++;
             pt.depth--;
-            if (pt.self_id >= 0)
-                self_hit(pt.o.x, pt.o.y, pt.o.z, pt.d.x, pt.d.y, pt.d.z, pt.inv_a, TMIN, sc.sph[pt.self_id],
-                         pt.self_id, best_t, best_id);
+            if (pt.self_id >= 0) self_hit(pt.o, pt.dh, tmin, sc.sph[pt.self_id], pt.self_id, best_t, best_id);
             if (best_id < 0) {
                 pt.L = pt.L + pt.T * sky(pt.d);
                 finished = true;
             } else {
                 float4 sph = sc.sph[best_id];
-                Hit h = finish_hit(pt.o, pt.d, best_t, sph);
+                Hit h = finish_hit(pt.o, pt.d, best_t * pt.inv_len, sph);
                 const DMat &m = sc.mats[sc.mat_id[best_id]];
                 float4 at = m.albedo_type, ef = m.emission_fuzz;
                 float ior = m.ior_pad.x;
@@ -234,9 +264,7 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KParams p, DeviceSce
                 } else {
                     pt.T = pt.T * att;
                     pt.o = no;
-                    pt.d = nd;
-                    pt.a = dot(nd, nd);
-                    pt.inv_a = 1.0f / pt.a;
+                    set_dir(pt, nd);
                     // diffuse and metal bounces start exactly on the sphere; the dielectric nudges its origin
                     pt.self_id = __float_as_uint(at.w) <= 1u ? best_id : -1;
                 }
@@ -331,7 +359,7 @@ __global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const
                                                                DeviceScene sc, int n_spheres, int32_t *__restrict__ id,
                                                                float *__restrict__ t, float *__restrict__ normal,
                                                                uint8_t *__restrict__ front) {
-    __shared__ float4 lds_sph[STREAM_TILE];
+    __shared__ float4 lds_sph[4 * STREAM_QUADS];
     const int i = blockIdx.x * WG_THREADS + threadIdx.x;
     const bool live = i < n_rays;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
@@ -339,16 +367,21 @@ __global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const
         o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
         d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
     }
-    float a = dot(d, d), inv_a = 1.0f / a;
-    float best_t = __builtin_inff();
+    const float a = dot(d, d);
+    const float inv_len = __frsqrt_rn(a), len = a * inv_len, inv_a = 1.0f / a;
+    const V3 dh = d * inv_len;
+    const RayK rk = make_rayk(o, dh);
+    float best_t = __builtin_inff(); // in units of |d| during the scan
     int best_id = -1;
-    for (int base = 0; base < n_spheres; base += STREAM_TILE) {
-        int cnt = min(STREAM_TILE, n_spheres - base);
+    const int nquads = (n_spheres + 3) / 4;
+    for (int base = 0; base < nquads; base += STREAM_QUADS) {
+        int cnt = min(STREAM_QUADS, nquads - base);
         __syncthreads();
-        for (int k = threadIdx.x; k < cnt; k += WG_THREADS) lds_sph[k] = sc.sph_r2[base + k];
+        for (int k = threadIdx.x; k < 4 * cnt; k += WG_THREADS) lds_sph[k] = sc.pairs[4 * base + k];
         __syncthreads();
-        if (live) scan_tile(lds_sph, cnt, base, o, d, a, inv_a, tmin, -1, best_t, best_id);
+        if (live) scan_lds(lds_sph, cnt, 4 * base, rk, tmin * len, -1, best_t, best_id);
     }
+    best_t *= inv_len;
     if (!REFINE) {
         if (!live) return;
         id[i] = best_id;
@@ -449,7 +482,9 @@ struct rt_ctx {
     int device = 0;
     std::string err;
     float4 *d_sph = nullptr;
-    float4 *d_sph_r2 = nullptr;
+    float4 *d_pairs = nullptr;
+    int n_quads = 0;
+    bool scalar_source = false;
     uint32_t *d_mat_id = nullptr;
     DMat *d_mats = nullptr;
     int n_spheres = 0;
@@ -475,10 +510,10 @@ int fail(rt_ctx *ctx, int code, const std::string &msg) {
 
 void free_scene(rt_ctx *ctx) {
     if (ctx->d_sph) (void)hipFree(ctx->d_sph);
-    if (ctx->d_sph_r2) (void)hipFree(ctx->d_sph_r2);
+    if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
     if (ctx->d_mat_id) (void)hipFree(ctx->d_mat_id);
     if (ctx->d_mats) (void)hipFree(ctx->d_mats);
-    ctx->d_sph = ctx->d_sph_r2 = nullptr;
+    ctx->d_sph = ctx->d_pairs = nullptr;
     ctx->d_mat_id = nullptr;
     ctx->d_mats = nullptr;
     ctx->have_scene = false;
@@ -536,11 +571,13 @@ RT_API int rt_create(int device, rt_ctx **out) {
         return RT_ERR_HIP;
     }
     // allow the render kernels their dynamic LDS budget
-    size_t lds_resident = 3072 + (size_t)RESIDENT_MAX * sizeof(float4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_resident);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_resident);
+    size_t lds_max = ACC_BYTES + (size_t)RESIDENT_MAX * sizeof(float4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_RESIDENT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_STREAMED>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    const char *src = getenv("RT_AMD_SPHERE_SOURCE"); // "lds" (default) or "scalar": tuning knob
+    ctx->scalar_source = src && strcmp(src, "scalar") == 0;
     *out = ctx;
     return RT_OK;
 }
@@ -568,13 +605,28 @@ RT_API int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_sphere
     free_scene(ctx);
     // keep at least one element allocated so kernels always get valid pointers
     size_t ns = (size_t)(n_spheres > 0 ? n_spheres : 1), nm = (size_t)(n_mats > 0 ? n_mats : 1);
-    std::vector<float4> sph(ns, make_float4(0, 0, 0, 0)), sph2(ns, make_float4(0, 0, 0, 0));
+    std::vector<float4> sph(ns, make_float4(0, 0, 0, 0));
     std::vector<uint32_t> mid(ns, 0);
     std::vector<DMat> mats(nm);
+    // pair-interleaved scan words: quads padded with spheres that cannot be hit
+    // (r^2 = -1 makes the discriminant negative for every ray), plus one spare quad so
+    // that a one-quad read-ahead never leaves the array
+    const int n_quads = (n_spheres + 3) / 4;
+    const size_t n_slots = (size_t)(n_quads + 2) * 4;
+    std::vector<float4> pairs(n_slots, make_float4(0, 0, 0, 0)); // n_slots spheres -> n_slots/2 pairs -> n_slots words
+    for (size_t i = 0; i < n_slots; ++i) {
+        float x = 0, y = 0, z = 0, r2 = -1.0f;
+        if ((int)i < n_spheres) {
+            const rt_sphere &sp = h_spheres[i];
+            x = sp.cx; y = sp.cy; z = sp.cz; r2 = sp.r * sp.r;
+        }
+        float4 &A = pairs[(i / 2) * 2], &B = pairs[(i / 2) * 2 + 1];
+        if (i % 2 == 0) { A.x = x; A.z = y; B.x = z; B.z = r2; }
+        else { A.y = x; A.w = y; B.y = z; B.w = r2; }
+    }
     for (int i = 0; i < n_spheres; ++i) {
-        const rt_sphere &s = h_spheres[i];
-        sph[i] = make_float4(s.cx, s.cy, s.cz, s.r);
-        sph2[i] = make_float4(s.cx, s.cy, s.cz, s.r * s.r);
+        const rt_sphere &sp = h_spheres[i];
+        sph[i] = make_float4(sp.cx, sp.cy, sp.cz, sp.r);
         mid[i] = h_mat_id[i];
     }
     for (size_t i = 0; i < nm; ++i) {
@@ -592,14 +644,15 @@ RT_API int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_sphere
         mats[i] = m;
     }
     HIP_TRY(ctx, hipMalloc(&ctx->d_sph, ns * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_sph_r2, ns * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_pairs, n_slots * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_mat_id, ns * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_mats, nm * sizeof(DMat)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_sph, sph.data(), ns * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_sph_r2, sph2.data(), ns * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_pairs, pairs.data(), n_slots * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_mat_id, mid.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_mats, mats.data(), nm * sizeof(DMat), hipMemcpyHostToDevice));
     ctx->n_spheres = n_spheres;
+    ctx->n_quads = n_quads;
     ctx->n_mats = n_mats;
     ctx->have_scene = true;
     return RT_OK;
@@ -632,26 +685,29 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     k.strip_first = p->strip_first;
     k.strip_stride = p->strip_stride;
     k.tiles_x = (p->width + WG_TILE_W - 1) / WG_TILE_W;
-    k.n_spheres = ctx->n_spheres;
+    k.n_quads = ctx->n_quads;
     k.inv_w = 1.0f / (float)p->width;
     k.inv_h = 1.0f / (float)p->height;
     memcpy(k.cam + 0, ctx->cam.center, 12);
     memcpy(k.cam + 3, ctx->cam.upper_left, 12);
     memcpy(k.cam + 6, ctx->cam.right, 12);
     memcpy(k.cam + 9, ctx->cam.down, 12);
-    DeviceScene sc{ctx->d_sph, ctx->d_sph_r2, ctx->d_mat_id, ctx->d_mats};
+    DeviceScene sc{ctx->d_sph, ctx->d_pairs, ctx->d_mat_id, ctx->d_mats};
     int nstrips = local_strips(p);
     if (nstrips == 0) return RT_OK;
     dim3 grid((unsigned)(nstrips * k.tiles_x)), block(WG_THREADS);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (ctx->n_spheres <= RESIDENT_MAX) {
-        size_t lds = 3072 + (size_t)(ctx->n_spheres > 0 ? ctx->n_spheres : 1) * sizeof(float4);
-        hipLaunchKernelGGL(render_kernel<false>, grid, block, lds, st, k, sc, (uchar4 *)d_rgba, (float4 *)d_accum,
-                           (unsigned long long *)d_rays);
+    uchar4 *o_rgba = (uchar4 *)d_rgba;
+    float4 *o_acc = (float4 *)d_accum;
+    unsigned long long *o_rays = (unsigned long long *)d_rays;
+    if (ctx->scalar_source) {
+        hipLaunchKernelGGL(render_kernel<SRC_SCALAR>, grid, block, ACC_BYTES, st, k, sc, o_rgba, o_acc, o_rays);
+    } else if (ctx->n_quads * 4 <= RESIDENT_MAX) {
+        size_t lds = ACC_BYTES + (size_t)(ctx->n_quads > 0 ? ctx->n_quads : 1) * 4 * sizeof(float4);
+        hipLaunchKernelGGL(render_kernel<SRC_LDS_RESIDENT>, grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays);
     } else {
-        size_t lds = 3072 + (size_t)STREAM_TILE * sizeof(float4);
-        hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, st, k, sc, (uchar4 *)d_rgba, (float4 *)d_accum,
-                           (unsigned long long *)d_rays);
+        size_t lds = ACC_BYTES + (size_t)STREAM_QUADS * 4 * sizeof(float4);
+        hipLaunchKernelGGL(render_kernel<SRC_LDS_STREAMED>, grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays);
     }
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
@@ -703,7 +759,7 @@ RT_API int rt_first_hit(rt_ctx *ctx, int n_rays, const float *d_org, const float
     if (n_rays == 0) return RT_OK;
     if (!d_org || !d_dir || !d_id) return fail(ctx, RT_ERR_INVALID, "null ray/id array");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DeviceScene sc{ctx->d_sph, ctx->d_sph_r2, ctx->d_mat_id, ctx->d_mats};
+    DeviceScene sc{ctx->d_sph, ctx->d_pairs, ctx->d_mat_id, ctx->d_mats};
     dim3 grid((unsigned)((n_rays + WG_THREADS - 1) / WG_THREADS)), block(WG_THREADS);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (flags & RT_FH_REFINE)

@@ -61,35 +61,54 @@ __device__ __forceinline__ V3 random_unit(float u0, float u1) {
 }
 
 // ---- ray / sphere ----------------------------------------------------------
-// One ray against one sphere, given as (centre, radius^2): the decision of
-// SphereObject::hitDetail up to the root selection (inc/RTObjects.h:135-149)
-// with Interval::surrounds' open interval (inc/RTGeometry.h:79-81).
-// `a` = d.d and inv_a = 1/a are per-ray constants.  Updates (best_t, best_id)
-// when the sphere is hit inside (tmin, best_t).
+// The scan works on a unit-length copy of the ray direction: with dh = d/|d| the
+// quadratic of SphereObject::hitDetail (inc/RTObjects.h:135-149) has a = 1 and its
+// roots are the reference's roots times |d|, so the interval (tmin, closest) is
+// scaled by |d| on entry and the winning root by 1/|d| on exit.
 //
-// Single-precision care, none of which changes the real-number result:
-//   * c = |oc|^2 - r^2 is accumulated onto -r^2 so the cancellation happens inside
-//     fused multiply-adds rather than after a rounded |oc|^2;
-//   * the two roots (-hb -+ sqrt(disc))/a are formed as q/a and c/q with
-//     q = -hb -+ sqrt(disc) taking the sign that adds magnitudes, so the root
-//     near the origin does not lose its digits to cancellation;
-//   * `self_id` names the sphere whose surface the ray starts on (-1: none).  Its
-//     constant term is exactly zero in real arithmetic but rounding noise of size
-//     ulp(|oc|)*r in floats, so it is skipped here and handled in closed form by
-//     self_hit() below.
-__device__ __forceinline__ void test_sphere(float ox, float oy, float oz, float dx, float dy, float dz, float a,
-                                            float inv_a, float tmin, float4 s, int idx, int self_id,
+// Spheres are stored in PAIRS so that one packed-FP32 instruction (v_pk_add_f32 /
+// v_pk_mul_f32 / v_pk_fma_f32) serves two spheres:
+//   word 2j   = (x0, x1, y0, y1)      word 2j+1 = (z0, z1, r0^2, r1^2)
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Ray operands replicated into both halves of a register pair.
+struct RayK {
+    f2 ox, oy, oz, dx, dy, dz;
+};
+
+__device__ __forceinline__ RayK make_rayk(V3 o, V3 dh) {
+    RayK r;
+    r.ox = (f2){o.x, o.x}; r.oy = (f2){o.y, o.y}; r.oz = (f2){o.z, o.z};
+    r.dx = (f2){dh.x, dh.x}; r.dy = (f2){dh.y, dh.y}; r.dz = (f2){dh.z, dh.z};
+    return r;
+}
+
+// hb = oc.dh, c = |oc|^2 - r^2, disc = hb^2 - c for two spheres: 10 packed instructions.
+// c is accumulated onto -r^2 so that the cancellation happens inside fused
+// multiply-adds rather than after a rounded |oc|^2.
+__device__ __forceinline__ void pair_disc(const RayK &r, float4 A, float4 B, f2 &hb, f2 &c, f2 &disc) {
+    f2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
+    f2 ocx = r.ox - cx, ocy = r.oy - cy, ocz = r.oz - cz;
+    hb = __builtin_elementwise_fma(ocx, r.dx, __builtin_elementwise_fma(ocy, r.dy, ocz * r.dz));
+    c = __builtin_elementwise_fma(ocx, ocx, __builtin_elementwise_fma(ocy, ocy, __builtin_elementwise_fma(ocz, ocz, -r2)));
+    disc = __builtin_elementwise_fma(hb, hb, -c);
+}
+
+// Root selection for one sphere whose discriminant is non-negative (the rare path):
+// Interval::surrounds' open interval (inc/RTGeometry.h:79-81), nearer root first.
+// The roots -hb -+ sqrt(disc) are formed as q and c/q with |q| = |hb| + sqrt(disc), so
+// the root near the origin does not lose its digits to cancellation.
+// `self_id` names the sphere whose surface the ray starts on (-1: none): its constant
+// term is exactly zero in real arithmetic but rounding noise of size ulp(|oc|)*r in
+// floats, so it is skipped here and handled in closed form by self_hit().
+__device__ __forceinline__ void resolve_hit(float hb, float c, float disc, float tmin, int idx, int self_id,
                                             float &best_t, int &best_id) {
-    float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
-    float hb = fmaf(ocx, dx, fmaf(ocy, dy, ocz * dz));
-    float c = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -s.w)));
-    float disc = fmaf(hb, hb, -(a * c));
     if (disc >= 0.0f) {
         float sq = __builtin_amdgcn_sqrtf(disc);
-        float q = hb < 0.0f ? sq - hb : -sq - hb; // |q| = |hb| + sq
-        float r0 = q * inv_a, r1 = c / q;
-        float t_near = hb < 0.0f ? r1 : r0;
-        float t_far = hb < 0.0f ? r0 : r1;
+        float q = hb < 0.0f ? sq - hb : -sq - hb;
+        float r1 = c / q;
+        float t_near = hb < 0.0f ? r1 : q;
+        float t_far = hb < 0.0f ? q : r1;
         float root = (t_near > tmin && t_near < best_t) ? t_near : t_far;
         if (root > tmin && root < best_t && idx != self_id) {
             best_t = root;
@@ -98,12 +117,27 @@ __device__ __forceinline__ void test_sphere(float ox, float oy, float oz, float 
     }
 }
 
+// Four spheres (two pair-words each) against one ray.
+__device__ __forceinline__ void test_quad(const RayK &r, float4 A0, float4 B0, float4 A1, float4 B1, float tmin,
+                                          int idx, int self_id, float &best_t, int &best_id) {
+    f2 hb0, c0, D0, hb1, c1, D1;
+    pair_disc(r, A0, B0, hb0, c0, D0);
+    pair_disc(r, A1, B1, hb1, c1, D1);
+    float m = fmaxf(fmaxf(D0.x, D0.y), fmaxf(D1.x, D1.y));
+    if (m >= 0.0f) {
+        resolve_hit(hb0.x, c0.x, D0.x, tmin, idx, self_id, best_t, best_id);
+        resolve_hit(hb0.y, c0.y, D0.y, tmin, idx + 1, self_id, best_t, best_id);
+        resolve_hit(hb1.x, c1.x, D1.x, tmin, idx + 2, self_id, best_t, best_id);
+        resolve_hit(hb1.y, c1.y, D1.y, tmin, idx + 3, self_id, best_t, best_id);
+    }
+}
+
 // The sphere a ray starts on: with the origin exactly on the surface the roots are
-// 0 and -2*hb/a; 0 is outside (tmin, .), so only the second can be a hit.
-__device__ __forceinline__ void self_hit(float ox, float oy, float oz, float dx, float dy, float dz, float inv_a,
-                                         float tmin, float4 sph, int self_id, float &best_t, int &best_id) {
-    float hb = fmaf(ox - sph.x, dx, fmaf(oy - sph.y, dy, (oz - sph.z) * dz));
-    float t = -2.0f * hb * inv_a;
+// 0 and -2*hb; 0 is outside (tmin, .), so only the second can be a hit.
+__device__ __forceinline__ void self_hit(V3 o, V3 dh, float tmin, float4 sph, int self_id, float &best_t,
+                                         int &best_id) {
+    float hb = fmaf(o.x - sph.x, dh.x, fmaf(o.y - sph.y, dh.y, (o.z - sph.z) * dh.z));
+    float t = -2.0f * hb;
     if (t > tmin && t < best_t) {
         best_t = t;
         best_id = self_id;
