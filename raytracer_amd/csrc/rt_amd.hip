@@ -33,22 +33,23 @@ namespace {
 
 constexpr int WG_THREADS = 256;
 constexpr int WAVES_PER_WG = 4;
-constexpr int WAVE_TILE = 8;                 // a wave owns WAVE_TILE x WAVE_TILE pixels
-constexpr int WG_TILE_W = WAVE_TILE * WAVES_PER_WG; // 32
-constexpr int WG_TILE_H = WAVE_TILE;         // 8 == RT_STRIP_ROWS
+constexpr int MAX_TILE_PX = 256;             // largest pixel tile a work item may cover (32 x 8)
 constexpr int RESIDENT_MAX = 4096;           // spheres kept resident in LDS (64 KiB)
 constexpr int STREAM_QUADS = 512;            // quads (4 spheres, 64 B) per streamed LDS tile (32 KiB)
-constexpr size_t ACC_BYTES = WAVES_PER_WG * 64 * 3 * sizeof(float); // LDS accumulators
+constexpr size_t ACC_BYTES = WAVES_PER_WG * MAX_TILE_PX * 3 * sizeof(float); // LDS accumulators
 constexpr float TMIN = 0.001f;               // CLOSEST_HIT_MIN_T, src/Camera.cpp:10
 
-static_assert(WG_TILE_H == RT_STRIP_ROWS, "strip height must equal the workgroup tile height");
+static_assert(RT_STRIP_ROWS == 8, "tile shapes below assume 8-row strips");
 
 struct KParams {
     int width, height;
     int spp, max_depth, sample_offset;
     uint32_t seed, flags;
     int strip_first, strip_stride;
-    int tiles_x;     // workgroup tiles per strip
+    int tile_w_log2, tile_h_log2; // work-item tile: 4x4, 8x8 or 32x8 pixels
+    int tiles_x;         // tiles across the image
+    int tiles_per_strip; // tiles_x * (8 / tile height)
+    int n_items;         // tiles this call renders
     int n_quads;     // sphere quads to scan (padding included)
     float inv_w, inv_h;
     float cam[12];   // center, upper_left, right, down
@@ -57,7 +58,7 @@ struct KParams {
 struct DeviceScene {
     const float4 *sph;    // cx, cy, cz, r
     const float4 *pairs;  // pair-interleaved (centre, r^2) words, see rt_device.h; padded with
-                          // never-hit spheres to a multiple of 4 plus one spare quad
+                          // never-hit spheres to a multiple of 16 plus two spare quads
     const uint32_t *mat_id;
     const DMat *mats;
 };
@@ -67,31 +68,66 @@ enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2 };
 
 // Scan `nquads` groups of four spheres held in LDS (every lane reads the same address:
 // a broadcast read) for one ray.
-__device__ __forceinline__ void scan_lds(const float4 *lds, int nquads, int base, const RayK &r, float tmin,
+__device__ __forceinline__ void scan_lds(const float4 *lds, int nquads, int base, const RayK &r, V3 o, V3 dh, float tmin,
                                          int self_id, float &best_t, int &best_id) {
-#pragma unroll 2
+#ifndef RT_UNROLL
+#define RT_UNROLL 1
+#endif
+#pragma unroll RT_UNROLL
     for (int q = 0; q < nquads; ++q) {
         float4 A0 = lds[4 * q], B0 = lds[4 * q + 1], A1 = lds[4 * q + 2], B1 = lds[4 * q + 3];
-        test_quad(r, A0, B0, A1, B1, tmin, base + 4 * q, self_id, best_t, best_id);
+        test_quad(r, o, dh, A0, B0, A1, B1, tmin, base + 4 * q, self_id, best_t, best_id);
     }
 }
 
-// Same scan with the sphere words fetched by wave-uniform loads straight from
-// global memory (scalar loads into SGPRs, served by the scalar cache): the words
-// become scalar operands of the packed instructions and no LDS read is issued.
-// The next quad is requested before the current one is tested.
-__device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, int nquads, const RayK &r, float tmin,
-                                            int self_id, float &best_t, int &best_id) {
-    float4 A0 = g[0], B0 = g[1], A1 = g[2], B1 = g[3];
+// Same scan with the sphere words fetched by scalar loads (s_load_dwordx16, one quad =
+// 64 bytes per instruction) straight from global memory through the scalar cache: the
+// words arrive in SGPRs and feed the packed instructions as scalar operands, so the scan
+// issues no LDS read and spends no VGPR on sphere data.  Scalar loads return out of
+// order, so the only safe wait is lgkmcnt(0); the loop keeps exactly one load in
+// flight: wait for quad q, request quad q+1, test quad q.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
+template <int BYTE_OFF>
+__device__ __forceinline__ u32x16 sload_quad(const float4 *p) {
+    u32x16 v;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "i"(BYTE_OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void swait_quads(u32x16 &a, u32x16 &b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory");
+}
+__device__ __forceinline__ float4 word(const u32x16 &v, int k) {
+    return make_float4(__uint_as_float(v[4 * k]), __uint_as_float(v[4 * k + 1]), __uint_as_float(v[4 * k + 2]),
+                       __uint_as_float(v[4 * k + 3]));
+}
+
+// nquads is a multiple of 4 (the list is padded with never-hit spheres) and two spare
+// quads follow it, so the read-ahead never leaves the array.  Two quads are requested
+// while two are tested.
+__device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, int nquads, const RayK &r, V3 o, V3 dh,
+                                            float tmin, int self_id, float &best_t, int &best_id) {
+    u32x16 A0 = sload_quad<0>(g), A1 = sload_quad<64>(g);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-    for (int q = 0; q < nquads; q += 2) {
-        const float4 *n1 = g + 4 * (q + 1); // the spare quad makes q + 1 and q + 2 always readable
-        float4 C0 = n1[0], D0 = n1[1], C1 = n1[2], D1 = n1[3];
-        test_quad(r, A0, B0, A1, B1, tmin, 4 * q, self_id, best_t, best_id);
-        const float4 *n2 = g + 4 * (q + 2);
-        A0 = n2[0]; B0 = n2[1]; A1 = n2[2]; B1 = n2[3];
-        if (q + 1 < nquads) test_quad(r, C0, D0, C1, D1, tmin, 4 * (q + 1), self_id, best_t, best_id);
+    for (int q = 0; q < nquads; q += 4) {
+        swait_quads(A0, A1);
+        u32x16 B0 = sload_quad<128>(g), B1 = sload_quad<192>(g);
+        __builtin_amdgcn_sched_barrier(0); // keep the requests ahead of the arithmetic they overlap with
+        test_quad(r, o, dh, word(A0, 0), word(A0, 1), word(A0, 2), word(A0, 3), tmin, 4 * q, self_id, best_t, best_id);
+        test_quad(r, o, dh, word(A1, 0), word(A1, 1), word(A1, 2), word(A1, 3), tmin, 4 * q + 4, self_id, best_t,
+                  best_id);
+        swait_quads(B0, B1);
+        g += 16; // four quads
+        A0 = sload_quad<0>(g);
+        A1 = sload_quad<64>(g);
+        __builtin_amdgcn_sched_barrier(0);
+        test_quad(r, o, dh, word(B0, 0), word(B0, 1), word(B0, 2), word(B0, 3), tmin, 4 * q + 8, self_id, best_t,
+                  best_id);
+        test_quad(r, o, dh, word(B1, 0), word(B1, 1), word(B1, 2), word(B1, 3), tmin, 4 * q + 12, self_id, best_t,
+                  best_id);
     }
+    swait_quads(A0, A1); // drain the read-ahead before the registers are reused
 }
 
 // Camera::genRay, src/Camera.cpp:124-135: jittered point on the 1x1 viewport.
@@ -130,33 +166,50 @@ __device__ __forceinline__ void set_dir(Path &pt, V3 d) {
     pt.dh = d * pt.inv_len;
 }
 
+// The tile of pixels one work item covers, decoded from the item index.
+struct Tile {
+    int x0, y0;   // top-left pixel
+    int vw, vh;   // valid width / height inside the image (<= 0: nothing to do)
+    int row0;     // output row of y0
+};
+
+__device__ __forceinline__ Tile decode_item(const KParams &p, unsigned item) {
+    Tile t;
+    int strip_local = (int)(item / (unsigned)p.tiles_per_strip);
+    int rem = (int)(item - (unsigned)strip_local * (unsigned)p.tiles_per_strip);
+    int sub_row = rem / p.tiles_x;
+    int tile_x = rem - sub_row * p.tiles_x;
+    int strip = p.strip_first + strip_local * p.strip_stride;
+    t.x0 = tile_x << p.tile_w_log2;
+    int dy = sub_row << p.tile_h_log2;
+    t.y0 = strip * RT_STRIP_ROWS + dy;
+    t.vw = min(1 << p.tile_w_log2, p.width - t.x0);
+    t.vh = min(1 << p.tile_h_log2, p.height - t.y0);
+    t.row0 = p.strip_stride == 1 ? t.y0 : strip_local * RT_STRIP_ROWS + dy;
+    return t;
+}
+
+// Persistent render kernel.  Work items are pixel tiles (all samples of 16, 64 or 256
+// pixels, chosen so that an item holds a few thousand samples); every wave pulls
+// items from one global counter until it runs dry, so the grid stays busy however
+// uneven the image is.  Inside an item the wave runs the path loop described at the
+// top of this file.
 template <int SRC>
-__global__ __launch_bounds__(WG_THREADS) void render_kernel(KParams p, DeviceScene sc, uchar4 *__restrict__ rgba,
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParams p, DeviceScene sc, uchar4 *__restrict__ rgba,
                                                             float4 *__restrict__ accum,
-                                                            unsigned long long *__restrict__ rays_out) {
+                                                            unsigned long long *__restrict__ rays_out,
+                                                            unsigned *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [0, 3 KiB): per-wave accumulators, 4 waves x 64 pixels x 3 floats; then the sphere words.
+    // [0, 12 KiB): per-wave accumulators, 4 waves x 3 channels x 256 pixels; then the sphere words.
     float *acc_all = reinterpret_cast<float *>(smem);
-    float4 *lds_sph = reinterpret_cast<float4 *>(smem + WAVES_PER_WG * 64 * 3 * sizeof(float));
+    float4 *lds_sph = reinterpret_cast<float4 *>(smem + ACC_BYTES);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float *acc = acc_all + wave * 192;
-
-    // which tile
-    const int strip_local = blockIdx.x / p.tiles_x;
-    const int tile_x = blockIdx.x - strip_local * p.tiles_x;
-    const int strip = p.strip_first + strip_local * p.strip_stride;
-    const int x0 = tile_x * WG_TILE_W + wave * WAVE_TILE;
-    const int y0 = strip * WG_TILE_H;
-    const int vw = min(WAVE_TILE, p.width - x0);  // valid pixels in x (may be <= 0)
-    const int vh = min(WAVE_TILE, p.height - y0);
-    const int nvalid = (vw > 0 && vh > 0) ? vw * vh : 0;
-    const uint32_t pool = (uint32_t)nvalid * (uint32_t)p.spp;
-
-    acc[lane] = 0.f;
-    acc[lane + 64] = 0.f;
-    acc[lane + 128] = 0.f;
+    float *acc = acc_all + wave * (3 * MAX_TILE_PX);
 
     const int nquads = p.n_quads; // groups of four spheres, padding included
     if (SRC == SRC_LDS_RESIDENT) {
@@ -171,25 +224,58 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KParams p, DeviceSce
     pt.gpix = pt.sample = pt.call = 0;
     pt.depth = 0;
     pt.self_id = -1;
-    uint32_t next_item = 0; // wave-uniform
     unsigned long long my_rays = 0;
-    bool need_work = true;
+    bool need_work = false;
+
+    // wave-uniform item state
+    bool have_item = false, queue_empty = false;
+    Tile tile = {0, 0, 0, 0, 0};
+    int nvalid = 0;
+    uint32_t pool = 0, next_sample = 0;
+    const int tile_px = 1 << (p.tile_w_log2 + p.tile_h_log2);
 
     for (;;) {
-        // ---- hand out work items to lanes that need one (ballot + prefix count) ----
+        // ---- take the next tile from the queue ----
+        if (!have_item && !queue_empty) {
+            unsigned it = 0;
+            if (lane == 0) it = atomicAdd(queue, 1u);
+            it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
+            if (it >= (unsigned)p.n_items) {
+                queue_empty = true;
+            } else {
+                tile = decode_item(p, it);
+                nvalid = (tile.vw > 0 && tile.vh > 0) ? tile.vw * tile.vh : 0;
+                pool = (uint32_t)nvalid * (uint32_t)p.spp;
+                next_sample = 0;
+                for (int q = lane; q < tile_px; q += 64) {
+                    acc[q] = 0.f;
+                    acc[MAX_TILE_PX + q] = 0.f;
+                    acc[2 * MAX_TILE_PX + q] = 0.f;
+                }
+                have_item = true;
+                need_work = true;
+            }
+        }
+        if (SRC == SRC_LDS_STREAMED) {
+            if (!__syncthreads_or(have_item)) break;
+        } else {
+            if (!have_item) break;
+        }
+
+        // ---- hand out samples to lanes that need one (ballot + prefix count) ----
         {
             unsigned long long m = __ballot(need_work);
             if (m) {
                 uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                uint32_t item = next_item + rank;
-                next_item += (uint32_t)__popcll(m);
+                uint32_t item = next_sample + rank;
+                next_sample += (uint32_t)__popcll(m);
                 if (need_work) {
                     if (item < pool) {
                         uint32_t q = item % (uint32_t)nvalid;
                         uint32_t smp = item / (uint32_t)nvalid;
-                        int lx = (int)(q % (uint32_t)vw), ly = (int)(q / (uint32_t)vw);
-                        pt.pix = ly * WAVE_TILE + lx;
-                        int px = x0 + lx, py = y0 + ly;
+                        int lx = (int)(q % (uint32_t)tile.vw), ly = (int)(q / (uint32_t)tile.vw);
+                        pt.pix = (ly << p.tile_w_log2) + lx;
+                        int px = tile.x0 + lx, py = tile.y0 + ly;
                         pt.gpix = (uint32_t)(py * p.width + px);
                         pt.sample = smp + (uint32_t)p.sample_offset;
                         uint32_t w0, w1, w2, w3;
@@ -213,12 +299,6 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KParams p, DeviceSce
         // a path with no depth left (max_depth == 0) contributes black and ends at once
         bool finished = pt.pix >= 0 && pt.depth <= 0;
 
-        if (SRC == SRC_LDS_STREAMED) {
-            if (!__syncthreads_or(active || finished)) break;
-        } else {
-            if (!__ballot(active || finished)) break;
-        }
-
         // ---- closest hit over all spheres (SceneManager::hitClosest, src/RayTracer.cpp:77-82) ----
         float best_t = __builtin_inff(); // in units of |d|
         int best_id = -1;
@@ -230,12 +310,12 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KParams p, DeviceSce
                 __syncthreads();
                 for (int i = threadIdx.x; i < 4 * cnt; i += WG_THREADS) lds_sph[i] = sc.pairs[4 * base + i];
                 __syncthreads();
-                if (active) scan_lds(lds_sph, cnt, 4 * base, rk, tmin, pt.self_id, best_t, best_id);
+                if (active) scan_lds(lds_sph, cnt, 4 * base, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
             }
         } else if (SRC == SRC_LDS_RESIDENT) {
-            if (active) scan_lds(lds_sph, nquads, 0, rk, tmin, pt.self_id, best_t, best_id);
+            if (active) scan_lds(lds_sph, nquads, 0, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
         } else {
-            if (active) scan_scalar(sc.pairs, nquads, rk, tmin, pt.self_id, best_t, best_id);
+            if (active) scan_scalar(sc.pairs, nquads, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
         }
 
         // ---- shade + bounce (Camera::getRayColor, src/Camera.cpp:137-157) ----
@@ -272,40 +352,42 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KParams p, DeviceSce
         }
         if (finished) {
             atomicAdd(&acc[pt.pix], pt.L.x);
-            atomicAdd(&acc[64 + pt.pix], pt.L.y);
-            atomicAdd(&acc[128 + pt.pix], pt.L.z);
+            atomicAdd(&acc[MAX_TILE_PX + pt.pix], pt.L.y);
+            atomicAdd(&acc[2 * MAX_TILE_PX + pt.pix], pt.L.z);
             pt.pix = -1;
             need_work = true;
         }
-    }
 
-    // ---- epilogue: lane l owns pixel l of the wave tile (convertRTColor, src/Camera.cpp:19-34) ----
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    {
-        int lx = lane & 7, ly = lane >> 3;
-        if (lx < vw && ly < vh) {
-            int px = x0 + lx;
-            int row = strip_local * WG_TILE_H + ly; // compact output row
-            if (p.strip_stride == 1) row = y0 + ly;
-            size_t o = (size_t)row * (size_t)p.width + (size_t)px;
-            float r = acc[lane], g = acc[64 + lane], b = acc[128 + lane];
-            float cnt = (float)p.spp;
-            if (accum) {
-                if (p.flags & RT_FLAG_ACCUMULATE) {
-                    float4 prev = accum[o];
-                    r += prev.x; g += prev.y; b += prev.z; cnt += prev.w;
+        // ---- tile done: tone-map and store (convertRTColor, src/Camera.cpp:19-34) ----
+        if (have_item && next_sample >= pool && !__ballot(pt.pix >= 0)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            for (int q = lane; q < tile_px; q += 64) {
+                int lx = q & ((1 << p.tile_w_log2) - 1), ly = q >> p.tile_w_log2;
+                if (lx < tile.vw && ly < tile.vh) {
+                    size_t o = (size_t)(tile.row0 + ly) * (size_t)p.width + (size_t)(tile.x0 + lx);
+                    float r = acc[q], g = acc[MAX_TILE_PX + q], b = acc[2 * MAX_TILE_PX + q];
+                    float cnt = (float)p.spp;
+                    if (accum) {
+                        if (p.flags & RT_FLAG_ACCUMULATE) {
+                            float4 prev = accum[o];
+                            r += prev.x; g += prev.y; b += prev.z; cnt += prev.w;
+                        }
+                        accum[o] = make_float4(r, g, b, cnt);
+                    }
+                    float inv = 1.0f / cnt;
+                    uchar4 px8;
+                    px8.x = (unsigned char)to_byte(r * inv);
+                    px8.y = (unsigned char)to_byte(g * inv);
+                    px8.z = (unsigned char)to_byte(b * inv);
+                    px8.w = 255;
+                    rgba[o] = px8;
                 }
-                accum[o] = make_float4(r, g, b, cnt);
             }
-            float inv = 1.0f / cnt;
-            uchar4 px8;
-            px8.x = (unsigned char)to_byte(r * inv);
-            px8.y = (unsigned char)to_byte(g * inv);
-            px8.z = (unsigned char)to_byte(b * inv);
-            px8.w = 255;
-            rgba[o] = px8;
+            have_item = false;
+            need_work = false;
         }
     }
+
     if (rays_out) {
         // wave-level sum, one atomic per wave
         for (int off = 32; off > 0; off >>= 1) my_rays += __shfl_down(my_rays, off, 64);
@@ -373,13 +455,13 @@ __global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const
     const RayK rk = make_rayk(o, dh);
     float best_t = __builtin_inff(); // in units of |d| during the scan
     int best_id = -1;
-    const int nquads = (n_spheres + 3) / 4;
+    const int nquads = ((n_spheres + 15) / 16) * 4; // as padded by rt_upload_scene
     for (int base = 0; base < nquads; base += STREAM_QUADS) {
         int cnt = min(STREAM_QUADS, nquads - base);
         __syncthreads();
         for (int k = threadIdx.x; k < 4 * cnt; k += WG_THREADS) lds_sph[k] = sc.pairs[4 * base + k];
         __syncthreads();
-        if (live) scan_lds(lds_sph, cnt, 4 * base, rk, tmin * len, -1, best_t, best_id);
+        if (live) scan_lds(lds_sph, cnt, 4 * base, rk, o, dh, tmin * len, -1, best_t, best_id);
     }
     best_t *= inv_len;
     if (!REFINE) {
@@ -484,7 +566,10 @@ struct rt_ctx {
     float4 *d_sph = nullptr;
     float4 *d_pairs = nullptr;
     int n_quads = 0;
-    bool scalar_source = false;
+    bool scalar_source = true;
+    unsigned *d_queue = nullptr; // work-item counter of the persistent render kernel (256 B, zeroed per launch)
+    int n_cus = 256;
+    int wgs_per_cu = 8;
     uint32_t *d_mat_id = nullptr;
     DMat *d_mats = nullptr;
     int n_spheres = 0;
@@ -576,8 +661,18 @@ RT_API int rt_create(int device, rt_ctx **out) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_STREAMED>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    const char *src = getenv("RT_AMD_SPHERE_SOURCE"); // "lds" (default) or "scalar": tuning knob
-    ctx->scalar_source = src && strcmp(src, "scalar") == 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->n_cus = prop.multiProcessorCount;
+    if (hipMalloc((void **)&ctx->d_queue, 256) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_HIP;
+    }
+    if (const char *w = getenv("RT_AMD_WGS_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 64) ctx->wgs_per_cu = v; }
+    // where the scan takes sphere data from: scalar loads (default, fastest measured) or LDS
+    // broadcast reads ("lds": resident copy for small scenes, streamed tiles for large ones)
+    const char *src = getenv("RT_AMD_SPHERE_SOURCE");
+    ctx->scalar_source = !(src && strcmp(src, "lds") == 0);
     *out = ctx;
     return RT_OK;
 }
@@ -586,6 +681,7 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     free_scene(ctx);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     delete ctx;
 }
 
@@ -611,7 +707,7 @@ RT_API int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_sphere
     // pair-interleaved scan words: quads padded with spheres that cannot be hit
     // (r^2 = -1 makes the discriminant negative for every ray), plus one spare quad so
     // that a one-quad read-ahead never leaves the array
-    const int n_quads = (n_spheres + 3) / 4;
+    const int n_quads = ((n_spheres + 15) / 16) * 4; // whole groups of four quads
     const size_t n_slots = (size_t)(n_quads + 2) * 4;
     std::vector<float4> pairs(n_slots, make_float4(0, 0, 0, 0)); // n_slots spheres -> n_slots/2 pairs -> n_slots words
     for (size_t i = 0; i < n_slots; ++i) {
@@ -684,7 +780,29 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     k.flags = p->flags;
     k.strip_first = p->strip_first;
     k.strip_stride = p->strip_stride;
-    k.tiles_x = (p->width + WG_TILE_W - 1) / WG_TILE_W;
+    // work-item tile: a few thousand samples per item keep a wave's pool much longer than its
+    // longest path; small frames get smaller tiles so that the queue still holds several
+    // items per resident wave
+    int nstrips = local_strips(p);
+    if (nstrips == 0) return RT_OK;
+    {
+        static const int shapes[3][2] = {{5, 3}, {3, 3}, {2, 2}}; // 32x8, 8x8, 4x4 (log2 w, log2 h)
+        const int spp = p->samples_per_pixel;
+        int pick = spp >= 256 ? 2 : (spp >= 64 ? 1 : 0);
+        auto items_of = [&](int i) {
+            long long tx = (p->width + (1 << shapes[i][0]) - 1) >> shapes[i][0];
+            return (long long)nstrips * tx * (RT_STRIP_ROWS >> shapes[i][1]);
+        };
+        const long long enough = 4LL * ctx->n_cus * 20;
+        while (pick < 2 && items_of(pick) < enough &&
+               (long long)spp << (shapes[pick + 1][0] + shapes[pick + 1][1]) >= 256)
+            ++pick;
+        k.tile_w_log2 = shapes[pick][0];
+        k.tile_h_log2 = shapes[pick][1];
+    }
+    const int tw = 1 << k.tile_w_log2, th = 1 << k.tile_h_log2;
+    k.tiles_x = (p->width + tw - 1) / tw;
+    k.tiles_per_strip = k.tiles_x * (RT_STRIP_ROWS / th);
     k.n_quads = ctx->n_quads;
     k.inv_w = 1.0f / (float)p->width;
     k.inv_h = 1.0f / (float)p->height;
@@ -693,21 +811,30 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     memcpy(k.cam + 6, ctx->cam.right, 12);
     memcpy(k.cam + 9, ctx->cam.down, 12);
     DeviceScene sc{ctx->d_sph, ctx->d_pairs, ctx->d_mat_id, ctx->d_mats};
-    int nstrips = local_strips(p);
-    if (nstrips == 0) return RT_OK;
-    dim3 grid((unsigned)(nstrips * k.tiles_x)), block(WG_THREADS);
+    long long items = (long long)nstrips * k.tiles_per_strip;
+    if (items > 0x7fffffffLL) return fail(ctx, RT_ERR_INVALID, "too many tiles for one call");
+    k.n_items = (int)items;
+    // persistent grid: enough workgroups to fill every CU at the kernel's occupancy; the
+    // item queue does the balancing, so more workgroups than that would only idle
+    long long want = (items + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    long long cap = (long long)ctx->n_cus * ctx->wgs_per_cu;
+    dim3 grid((unsigned)(want < cap ? want : cap)), block(WG_THREADS);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     uchar4 *o_rgba = (uchar4 *)d_rgba;
     float4 *o_acc = (float4 *)d_accum;
     unsigned long long *o_rays = (unsigned long long *)d_rays;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 256, st));
     if (ctx->scalar_source) {
-        hipLaunchKernelGGL(render_kernel<SRC_SCALAR>, grid, block, ACC_BYTES, st, k, sc, o_rgba, o_acc, o_rays);
+        hipLaunchKernelGGL(render_kernel<SRC_SCALAR>, grid, block, ACC_BYTES, st, k, sc, o_rgba, o_acc, o_rays,
+                           ctx->d_queue);
     } else if (ctx->n_quads * 4 <= RESIDENT_MAX) {
         size_t lds = ACC_BYTES + (size_t)(ctx->n_quads > 0 ? ctx->n_quads : 1) * 4 * sizeof(float4);
-        hipLaunchKernelGGL(render_kernel<SRC_LDS_RESIDENT>, grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays);
+        hipLaunchKernelGGL(render_kernel<SRC_LDS_RESIDENT>, grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays,
+                           ctx->d_queue);
     } else {
         size_t lds = ACC_BYTES + (size_t)STREAM_QUADS * 4 * sizeof(float4);
-        hipLaunchKernelGGL(render_kernel<SRC_LDS_STREAMED>, grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays);
+        hipLaunchKernelGGL(render_kernel<SRC_LDS_STREAMED>, grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays,
+                           ctx->d_queue);
     }
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;

@@ -71,64 +71,76 @@ __device__ __forceinline__ V3 random_unit(float u0, float u1) {
 //   word 2j   = (x0, x1, y0, y1)      word 2j+1 = (z0, z1, r0^2, r1^2)
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// Ray operands replicated into both halves of a register pair.
+// Ray operands of the scan, replicated into both halves of a register pair:
+// the unit direction dh and the moment m = O x dh of the ray's line.
 struct RayK {
-    f2 ox, oy, oz, dx, dy, dz;
+    f2 dx, dy, dz, mx, my, mz;
 };
 
 __device__ __forceinline__ RayK make_rayk(V3 o, V3 dh) {
     RayK r;
-    r.ox = (f2){o.x, o.x}; r.oy = (f2){o.y, o.y}; r.oz = (f2){o.z, o.z};
+    float mx = fmaf(o.y, dh.z, -(o.z * dh.y));
+    float my = fmaf(o.z, dh.x, -(o.x * dh.z));
+    float mz = fmaf(o.x, dh.y, -(o.y * dh.x));
     r.dx = (f2){dh.x, dh.x}; r.dy = (f2){dh.y, dh.y}; r.dz = (f2){dh.z, dh.z};
+    r.mx = (f2){mx, mx}; r.my = (f2){my, my}; r.mz = (f2){mz, mz};
     return r;
 }
 
-// hb = oc.dh, c = |oc|^2 - r^2, disc = hb^2 - c for two spheres: 10 packed instructions.
-// c is accumulated onto -r^2 so that the cancellation happens inside fused
-// multiply-adds rather than after a rounded |oc|^2.
-__device__ __forceinline__ void pair_disc(const RayK &r, float4 A, float4 B, f2 &hb, f2 &c, f2 &disc) {
+// Discriminant of two spheres in 9 packed FMAs.  With |dh| = 1,
+//   disc = hb^2 - c = r^2 - |(O - C) x dh|^2,   (O - C) x dh = m - C x dh,
+// i.e. the squared radius minus the squared distance from the centre to the ray's
+// line.  Rounding errors enter linearly in the coordinates (never through a rounded
+// |O|^2 or |C|^2), and every instruction is a fused multiply-add.
+__device__ __forceinline__ f2 pair_disc(const RayK &r, float4 A, float4 B) {
     f2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
-    f2 ocx = r.ox - cx, ocy = r.oy - cy, ocz = r.oz - cz;
-    hb = __builtin_elementwise_fma(ocx, r.dx, __builtin_elementwise_fma(ocy, r.dy, ocz * r.dz));
-    c = __builtin_elementwise_fma(ocx, ocx, __builtin_elementwise_fma(ocy, ocy, __builtin_elementwise_fma(ocz, ocz, -r2)));
-    disc = __builtin_elementwise_fma(hb, hb, -c);
+    f2 wx = __builtin_elementwise_fma(cz, r.dy, __builtin_elementwise_fma(-cy, r.dz, r.mx));
+    f2 wy = __builtin_elementwise_fma(cx, r.dz, __builtin_elementwise_fma(-cz, r.dx, r.my));
+    f2 wz = __builtin_elementwise_fma(cy, r.dx, __builtin_elementwise_fma(-cx, r.dy, r.mz));
+    return __builtin_elementwise_fma(-wx, wx, __builtin_elementwise_fma(-wy, wy, __builtin_elementwise_fma(-wz, wz, r2)));
 }
 
 // Root selection for one sphere whose discriminant is non-negative (the rare path):
+// the roots of SphereObject::hitDetail (inc/RTObjects.h:143-149) with
 // Interval::surrounds' open interval (inc/RTGeometry.h:79-81), nearer root first.
-// The roots -hb -+ sqrt(disc) are formed as q and c/q with |q| = |hb| + sqrt(disc), so
-// the root near the origin does not lose its digits to cancellation.
+// hb = oc.dh and c = |oc|^2 - r^2 are formed here from oc = O - C (c accumulated onto
+// -r^2 so that the cancellation happens inside the fused multiply-adds); the roots
+// -hb -+ sqrt(disc) are taken as q and c/q with |q| = |hb| + sqrt(disc), so the root
+// near the origin does not lose its digits to cancellation.
 // `self_id` names the sphere whose surface the ray starts on (-1: none): its constant
 // term is exactly zero in real arithmetic but rounding noise of size ulp(|oc|)*r in
 // floats, so it is skipped here and handled in closed form by self_hit().
-__device__ __forceinline__ void resolve_hit(float hb, float c, float disc, float tmin, int idx, int self_id,
-                                            float &best_t, int &best_id) {
+__device__ __forceinline__ void resolve_hit(V3 o, V3 dh, float cx, float cy, float cz, float r2, float disc,
+                                            float tmin, int idx, int self_id, float &best_t, int &best_id) {
     if (disc >= 0.0f) {
+        float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
+        float hb = fmaf(ocx, dh.x, fmaf(ocy, dh.y, ocz * dh.z));
+        float c = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -r2)));
         float sq = __builtin_amdgcn_sqrtf(disc);
-        float q = hb < 0.0f ? sq - hb : -sq - hb;
-        float r1 = c / q;
-        float t_near = hb < 0.0f ? r1 : q;
-        float t_far = hb < 0.0f ? q : r1;
-        float root = (t_near > tmin && t_near < best_t) ? t_near : t_far;
-        if (root > tmin && root < best_t && idx != self_id) {
-            best_t = root;
+        float q = -(hb + __builtin_copysignf(sq, hb)); // |q| = |hb| + sq
+        float r1 = c * __builtin_amdgcn_rcpf(q);
+        float t_near = fminf(q, r1), t_far = fmaxf(q, r1);
+        // the reference takes the nearer root if it lies in (tmin, best_t), else the farther
+        // one if that does; a nearer root >= best_t rules the farther one out as well
+        float cand = t_near > tmin ? t_near : t_far;
+        if (cand > tmin && cand < best_t && idx != self_id) {
+            best_t = cand;
             best_id = idx;
         }
     }
 }
 
 // Four spheres (two pair-words each) against one ray.
-__device__ __forceinline__ void test_quad(const RayK &r, float4 A0, float4 B0, float4 A1, float4 B1, float tmin,
-                                          int idx, int self_id, float &best_t, int &best_id) {
-    f2 hb0, c0, D0, hb1, c1, D1;
-    pair_disc(r, A0, B0, hb0, c0, D0);
-    pair_disc(r, A1, B1, hb1, c1, D1);
+__device__ __forceinline__ void test_quad(const RayK &r, V3 o, V3 dh, float4 A0, float4 B0, float4 A1, float4 B1,
+                                          float tmin, int idx, int self_id, float &best_t, int &best_id) {
+    f2 D0 = pair_disc(r, A0, B0);
+    f2 D1 = pair_disc(r, A1, B1);
     float m = fmaxf(fmaxf(D0.x, D0.y), fmaxf(D1.x, D1.y));
     if (m >= 0.0f) {
-        resolve_hit(hb0.x, c0.x, D0.x, tmin, idx, self_id, best_t, best_id);
-        resolve_hit(hb0.y, c0.y, D0.y, tmin, idx + 1, self_id, best_t, best_id);
-        resolve_hit(hb1.x, c1.x, D1.x, tmin, idx + 2, self_id, best_t, best_id);
-        resolve_hit(hb1.y, c1.y, D1.y, tmin, idx + 3, self_id, best_t, best_id);
+        resolve_hit(o, dh, A0.x, A0.z, B0.x, B0.z, D0.x, tmin, idx, self_id, best_t, best_id);
+        resolve_hit(o, dh, A0.y, A0.w, B0.y, B0.w, D0.y, tmin, idx + 1, self_id, best_t, best_id);
+        resolve_hit(o, dh, A1.x, A1.z, B1.x, B1.z, D1.x, tmin, idx + 2, self_id, best_t, best_id);
+        resolve_hit(o, dh, A1.y, A1.w, B1.y, B1.w, D1.y, tmin, idx + 3, self_id, best_t, best_id);
     }
 }
 
