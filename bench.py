@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu rehearse the N > 1 path on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -89,11 +92,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     cfg = dict(WORKLOADS[args.workload])
     if args.spp:
@@ -106,7 +114,7 @@ def main():
     r.set_scene(scene)
     p = RenderParams(W, H, samples_per_pixel=cfg["spp"], max_depth=cfg["depth"], seed=0,
                      strip_first=rank, strip_stride=world)
-    gather = StripGather(W, H, rank, world, dev)
+    gather = StripGather(W, H, rank, world, dev, stage_on_host=(args.backend == "gloo"))
     rgba = gather.local_buffer()
     accum = torch.zeros((rgba.shape[0], W, 4), dtype=torch.float32, device=dev)
     rays = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -140,8 +148,9 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
-    t = torch.tensor([dt, sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device=dev)
-    rays_total = rays.clone()
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([dt, sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device=red_dev)
+    rays_total = rays.clone().to(red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)

@@ -34,11 +34,13 @@ def local_rows(height: int, rank: int, world: int) -> int:
 
 class StripGather:
     def __init__(self, width: int, height: int, rank: int, world: int, device, channels: int = 4,
-                 dtype=torch.uint8):
+                 dtype=torch.uint8, stage_on_host: bool = False):
         self.W, self.H, self.rank, self.world = width, height, rank, world
         self.device = device
         self.channels, self.dtype = channels, dtype
         self.max_strips = local_strip_count(height, 0, world)  # rank 0 never has fewer strips than others
+        # stage_on_host: the process group cannot move device tensors (gloo): copy through the host
+        self.stage_on_host = stage_on_host and world > 1 and torch.device(device).type != "cpu"
         if world > 1:
             shape = (self.max_strips * STRIP_ROWS, width, channels)
             self._send = torch.zeros(shape, dtype=dtype, device=device)
@@ -60,7 +62,15 @@ class StripGather:
             return local
         if local.data_ptr() != self._send.data_ptr() and local.numel():
             self._send[: local.shape[0]].copy_(local)
-        dist.gather(self._send, self._recv if self.rank == 0 else None, dst=0)
+        if self.stage_on_host:
+            send = self._send.cpu()
+            recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(send, recv, dst=0)
+            if self.rank == 0:
+                for dst, src in zip(self._recv, recv):
+                    dst.copy_(src)
+        else:
+            dist.gather(self._send, self._recv if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
         total = n_strips(self.H)

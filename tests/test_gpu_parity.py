@@ -364,3 +364,21 @@ def test_gpu_tonemap_and_sky_kats(renderer):
     assert np.allclose(acc[:, :, :3].reshape(-1, 3), want, atol=2e-6)
     want8 = np.floor(256 * np.clip(np.sqrt(want), 0, 0.999)).astype(np.uint8)
     assert np.mean(rgba[:, :, :3].reshape(-1, 3) != want8) <= 0.05  # a value may sit on a rounding edge
+
+
+def test_sphere_source_knob_changes_no_byte(monkeypatch):
+    """The LDS-staged scan (resident and streamed) and the scalar-load scan run the same arithmetic."""
+    from raytracer_amd import Renderer
+
+    for scene, p in ((scenes.random_spheres_scene(), RenderParams(160, 88, 32, 20, seed=4)),
+                     (scenes.grid_scene(72, 72), RenderParams(64, 40, 8, 12, seed=4))):
+        imgs = []
+        for src in ("scalar", "lds"):
+            monkeypatch.setenv("RT_AMD_SPHERE_SOURCE", src)
+            r = Renderer(0)
+            r.set_scene(scene)
+            imgs.append(r.render_host(p, want_accum=True))
+            r.close()
+        assert np.array_equal(imgs[0][0], imgs[1][0])
+        assert np.array_equal(imgs[0][1], imgs[1][1])
+        assert imgs[0][2] == imgs[1][2]
