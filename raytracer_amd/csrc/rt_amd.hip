@@ -58,7 +58,7 @@ struct KParams {
 struct DeviceScene {
     const float4 *sph;    // cx, cy, cz, r
     const float4 *pairs;  // pair-interleaved (centre, r^2) words, see rt_device.h; padded with
-                          // never-hit spheres to a multiple of 16 plus two spare quads
+                          // never-hit spheres to a multiple of 8 plus four spare quads
     const uint32_t *mat_id;
     const DMat *mats;
 };
@@ -102,9 +102,9 @@ __device__ __forceinline__ float4 word(const u32x16 &v, int k) {
                        __uint_as_float(v[4 * k + 3]));
 }
 
-// nquads is a multiple of 4 (the list is padded with never-hit spheres) and two spare
-// quads follow it, so the read-ahead never leaves the array.  Two quads are requested
-// while two are tested.
+// nquads is even (the list is padded with never-hit spheres) and four spare quads follow
+// it, so the read-ahead never leaves the array.  Two quads are requested while two are
+// tested.
 __device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, int nquads, const RayK &r, V3 o, V3 dh,
                                             float tmin, int self_id, float &best_t, int &best_id) {
     u32x16 A0 = sload_quad<0>(g), A1 = sload_quad<64>(g);
@@ -122,10 +122,12 @@ __device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, int nq
         A0 = sload_quad<0>(g);
         A1 = sload_quad<64>(g);
         __builtin_amdgcn_sched_barrier(0);
-        test_quad(r, o, dh, word(B0, 0), word(B0, 1), word(B0, 2), word(B0, 3), tmin, 4 * q + 8, self_id, best_t,
-                  best_id);
-        test_quad(r, o, dh, word(B1, 0), word(B1, 1), word(B1, 2), word(B1, 3), tmin, 4 * q + 12, self_id, best_t,
-                  best_id);
+        if (q + 2 < nquads) {
+            test_quad(r, o, dh, word(B0, 0), word(B0, 1), word(B0, 2), word(B0, 3), tmin, 4 * q + 8, self_id, best_t,
+                      best_id);
+            test_quad(r, o, dh, word(B1, 0), word(B1, 1), word(B1, 2), word(B1, 3), tmin, 4 * q + 12, self_id,
+                      best_t, best_id);
+        }
     }
     swait_quads(A0, A1); // drain the read-ahead before the registers are reused
 }
@@ -231,7 +233,8 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
     bool have_item = false, queue_empty = false;
     Tile tile = {0, 0, 0, 0, 0};
     int nvalid = 0;
-    uint32_t pool = 0, next_sample = 0;
+    int cur_q = 0, cur_smp = 0;         // next (pixel, sample) of the item's pool, pixels fastest
+    float inv_nvalid = 0.f, inv_vw = 0.f; // reciprocals for the small index divisions below
     const int tile_px = 1 << (p.tile_w_log2 + p.tile_h_log2);
 
     for (;;) {
@@ -245,8 +248,10 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
             } else {
                 tile = decode_item(p, it);
                 nvalid = (tile.vw > 0 && tile.vh > 0) ? tile.vw * tile.vh : 0;
-                pool = (uint32_t)nvalid * (uint32_t)p.spp;
-                next_sample = 0;
+                inv_nvalid = nvalid > 0 ? 1.0f / (float)nvalid : 0.f;
+                inv_vw = tile.vw > 0 ? 1.0f / (float)tile.vw : 0.f;
+                cur_q = 0;
+                cur_smp = nvalid > 0 ? 0 : p.spp; // an empty tile has an empty pool
                 for (int q = lane; q < tile_px; q += 64) {
                     acc[q] = 0.f;
                     acc[MAX_TILE_PX + q] = 0.f;
@@ -262,39 +267,6 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
             if (!have_item) break;
         }
 
-        // ---- hand out samples to lanes that need one (ballot + prefix count) ----
-        {
-            unsigned long long m = __ballot(need_work);
-            if (m) {
-                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                uint32_t item = next_sample + rank;
-                next_sample += (uint32_t)__popcll(m);
-                if (need_work) {
-                    if (item < pool) {
-                        uint32_t q = item % (uint32_t)nvalid;
-                        uint32_t smp = item / (uint32_t)nvalid;
-                        int lx = (int)(q % (uint32_t)tile.vw), ly = (int)(q / (uint32_t)tile.vw);
-                        pt.pix = (ly << p.tile_w_log2) + lx;
-                        int px = tile.x0 + lx, py = tile.y0 + ly;
-                        pt.gpix = (uint32_t)(py * p.width + px);
-                        pt.sample = smp + (uint32_t)p.sample_offset;
-                        uint32_t w0, w1, w2, w3;
-                        rng4(pt.gpix, pt.sample, 0u, p.seed, w0, w1, w2, w3);
-                        V3 d;
-                        gen_ray(p, px, py, u01(w0), u01(w1), pt.o, d);
-                        set_dir(pt, d);
-                        pt.T = mk(1, 1, 1);
-                        pt.L = mk(0, 0, 0);
-                        pt.call = 1;
-                        pt.depth = p.max_depth;
-                        pt.self_id = -1;
-                    } else {
-                        pt.pix = -1;
-                    }
-                    need_work = false;
-                }
-            }
-        }
         const bool active = pt.pix >= 0 && pt.depth > 0;
         // a path with no depth left (max_depth == 0) contributes black and ends at once
         bool finished = pt.pix >= 0 && pt.depth <= 0;
@@ -318,7 +290,13 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
             if (active) scan_scalar(sc.pairs, nquads, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
         }
 
-        // ---- shade + bounce (Camera::getRayColor, src/Camera.cpp:137-157) ----
+        // ---- shade (Camera::getRayColor, src/Camera.cpp:137-157) ----
+        bool bounce = false;
+        Hit h;
+        h.p = h.n = mk(0, 0, 0);
+        h.front = false;
+        float4 at = make_float4(0, 0, 0, 0), ef = make_float4(0, 0, 0, 0);
+        float ior = 1.f;
         if (active) {
             my_rays++;
             pt.depth--;
@@ -327,27 +305,16 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
                 pt.L = pt.L + pt.T * sky(pt.d);
                 finished = true;
             } else {
-                float4 sph = sc.sph[best_id];
-                Hit h = finish_hit(pt.o, pt.d, best_t * pt.inv_len, sph);
+                h = finish_hit(pt.o, pt.d, best_t * pt.inv_len, sc.sph[best_id]);
                 const DMat &m = sc.mats[sc.mat_id[best_id]];
-                float4 at = m.albedo_type, ef = m.emission_fuzz;
-                float ior = m.ior_pad.x;
+                at = m.albedo_type;
+                ef = m.emission_fuzz;
+                ior = m.ior_pad.x;
                 pt.L = pt.L + pt.T * mk(ef.x, ef.y, ef.z);
-                uint32_t w0, w1, w2, w3;
-                rng4(pt.gpix, pt.sample, pt.call, p.seed, w0, w1, w2, w3);
-                pt.call++;
-                V3 att, no, nd;
-                bool ok = scatter(__float_as_uint(at.w), mk(at.x, at.y, at.z), ef.w, ior, pt.d, h, u01(w0), u01(w1),
-                                  u01(w2), att, no, nd);
-                if (!ok || pt.depth == 0) {
-                    finished = true;
-                } else {
-                    pt.T = pt.T * att;
-                    pt.o = no;
-                    set_dir(pt, nd);
-                    // diffuse and metal bounces start exactly on the sphere; the dielectric nudges its origin
-                    pt.self_id = __float_as_uint(at.w) <= 1u ? best_id : -1;
-                }
+                // an emissive surface ends the path (RTEmissive::scatter, inc/RTMaterial.h:205-207); so does
+                // running out of depth: the next getRayColor would return black (src/Camera.cpp:138)
+                if (__float_as_uint(at.w) == 3u || pt.depth == 0) finished = true;
+                else bounce = true;
             }
         }
         if (finished) {
@@ -358,8 +325,70 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
             need_work = true;
         }
 
+        // ---- hand the next (pixel, sample) of the pool to every lane without a path:
+        //      ballot + prefix count, so the wave stays full until the pool is empty ----
+        bool fresh = false;
+        int px = 0, py = 0;
+        {
+            unsigned long long m = __ballot(need_work);
+            if (m) {
+                int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (need_work) {
+                    // idx < nvalid + 64 <= 320 and q < 256: the float reciprocals divide exactly
+                    int idx = cur_q + rank;
+                    int wraps = (int)(((float)idx + 0.5f) * inv_nvalid);
+                    int q = idx - wraps * nvalid;
+                    int smp = cur_smp + wraps;
+                    if (smp < p.spp) {
+                        int ly = (int)(((float)q + 0.5f) * inv_vw);
+                        int lx = q - ly * tile.vw;
+                        pt.pix = (ly << p.tile_w_log2) + lx;
+                        px = tile.x0 + lx;
+                        py = tile.y0 + ly;
+                        pt.gpix = (uint32_t)(py * p.width + px);
+                        pt.sample = (uint32_t)(smp + p.sample_offset);
+                        pt.call = 0;
+                        pt.T = mk(1, 1, 1);
+                        pt.L = mk(0, 0, 0);
+                        pt.depth = p.max_depth;
+                        pt.self_id = -1;
+                        fresh = true;
+                    }
+                    need_work = false;
+                }
+                if (cur_smp < p.spp) {
+                    cur_q += (int)__popcll(m);
+                    while (cur_q >= nvalid) {
+                        cur_q -= nvalid;
+                        ++cur_smp;
+                    }
+                }
+            }
+        }
+
+        // ---- the next ray of every lane that has one to make: a primary ray (Camera::genRay,
+        //      src/Camera.cpp:124-135) or a bounce (RTMaterial::scatter); one random draw serves both ----
+        if (fresh || bounce) {
+            uint32_t w0, w1, w2, w3;
+            rng4(pt.gpix, pt.sample, pt.call, p.seed, w0, w1, w2, w3);
+            pt.call++;
+            V3 nd;
+            if (fresh) {
+                gen_ray(p, px, py, u01(w0), u01(w1), pt.o, nd);
+            } else {
+                V3 att, no;
+                scatter(__float_as_uint(at.w), mk(at.x, at.y, at.z), ef.w, ior, pt.d, h, u01(w0), u01(w1), u01(w2), att,
+                        no, nd);
+                pt.T = pt.T * att;
+                pt.o = no;
+                // diffuse and metal bounces start exactly on the sphere; the dielectric nudges its origin
+                pt.self_id = __float_as_uint(at.w) <= 1u ? best_id : -1;
+            }
+            set_dir(pt, nd);
+        }
+
         // ---- tile done: tone-map and store (convertRTColor, src/Camera.cpp:19-34) ----
-        if (have_item && next_sample >= pool && !__ballot(pt.pix >= 0)) {
+        if (have_item && cur_smp >= p.spp && !__ballot(pt.pix >= 0)) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             for (int q = lane; q < tile_px; q += 64) {
                 int lx = q & ((1 << p.tile_w_log2) - 1), ly = q >> p.tile_w_log2;
@@ -455,7 +484,7 @@ __global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const
     const RayK rk = make_rayk(o, dh);
     float best_t = __builtin_inff(); // in units of |d| during the scan
     int best_id = -1;
-    const int nquads = ((n_spheres + 15) / 16) * 4; // as padded by rt_upload_scene
+    const int nquads = ((n_spheres + 7) / 8) * 2; // as padded by rt_upload_scene
     for (int base = 0; base < nquads; base += STREAM_QUADS) {
         int cnt = min(STREAM_QUADS, nquads - base);
         __syncthreads();
@@ -707,8 +736,8 @@ RT_API int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_sphere
     // pair-interleaved scan words: quads padded with spheres that cannot be hit
     // (r^2 = -1 makes the discriminant negative for every ray), plus one spare quad so
     // that a one-quad read-ahead never leaves the array
-    const int n_quads = ((n_spheres + 15) / 16) * 4; // whole groups of four quads
-    const size_t n_slots = (size_t)(n_quads + 2) * 4;
+    const int n_quads = ((n_spheres + 7) / 8) * 2; // an even number of quads
+    const size_t n_slots = (size_t)(n_quads + 4) * 4;
     std::vector<float4> pairs(n_slots, make_float4(0, 0, 0, 0)); // n_slots spheres -> n_slots/2 pairs -> n_slots words
     for (size_t i = 0; i < n_slots; ++i) {
         float x = 0, y = 0, z = 0, r2 = -1.0f;

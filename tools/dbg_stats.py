@@ -7,11 +7,12 @@ r=Renderer(0); s=scenes.random_spheres_scene(); r.set_scene(s)
 lib=api.load_library()
 out=(C.c_ulonglong*8)()
 lib.rt_debug_read(out)
-p=RenderParams(1200,675,samples_per_pixel=20,max_depth=50)
+p=RenderParams(1200,675,samples_per_pixel=500,max_depth=50)
 rgba,acc,rays=r.render_host(p)
 lib.rt_debug_read(out)
 o=list(out)
-nq=(s.n_spheres+3)//4
-print('rays',rays,'wave-scans(ideal)',rays/64,'quads/scan',nq)
-print('branch taken (wave-level)',o[0],'per wave-scan',o[0]/(rays/64),'of',nq,' avg lanes in branch',o[1]/max(o[0],1))
-print('lane-level disc>=0 events',o[2],'per ray',o[2]/rays,' accepted',o[3],'per ray',o[3]/rays)
+nq=((s.n_spheres+7)//8)*2
+print('rays',rays,'ideal wave-scans',rays/64,'quads/scan',nq)
+print('loop iterations',o[4],' with any active lane',o[6],' active lanes per scanning iteration',o[5]/max(o[6],1))
+print('quad-branch entries',o[0],'per scan',o[0]/max(o[6],1),' avg lanes',o[1]/max(o[0],1))
+print('resolve entries (wave-level)',o[2],'per scan',o[2]/max(o[6],1),' avg lanes',o[3]/max(o[2],1))
