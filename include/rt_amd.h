@@ -59,6 +59,9 @@ typedef struct rt_sphere {
  *   fuzz     : RTMetal::fuzz_ (already clamped to <= 1 by the constructor, :103)
  *   ior      : RTDielectric::refractionIndex_ (:137)
  *   emission : RTMaterial::emission_ — honoured for every kind, as emitted() is (:37)
+ *   diffuse  : RTMaterial::diffuse_ as read by Light::getDirectLighting
+ *              (inc/RTObjects.h:251-252); zero for metal / dielectric / emissive unless the
+ *              caller set it through the reference getter.  Only used with lights.
  */
 typedef struct rt_material {
     uint32_t type;
@@ -66,8 +69,19 @@ typedef struct rt_material {
     float fuzz;
     float ior;
     float emission[3];
-    float _pad;
+    float diffuse[3];
 } rt_material;
+
+/* One Phong point light: the fields of class Light (reference inc/RTObjects.h:220-226). */
+typedef struct rt_light {
+    float position[3];
+    float ambient[3];   /* ambientIntensity_  */
+    float diffuse[3];   /* defuseIntensity_   */
+    float specular[3];  /* specularIntensity_ (stored by the reference but never read: the
+                           specular term is pow(cos, viewLightPow) in white, :309-320) */
+    float view_pow;     /* viewLightPow_      */
+    float _pad[3];
+} rt_light;
 
 /* Camera state the kernels need: Camera::center_ and the three Viewport vectors
  * produced by Camera::updateViewPort (reference src/Camera.cpp:206-221,
@@ -81,8 +95,11 @@ typedef struct rt_camera {
 
 /* Render flags */
 enum {
-    RT_FLAG_ACCUMULATE = 1u << 0 /* add to d_accum instead of overwriting it; the
-                                    8-bit image is then made from the running mean */
+    RT_FLAG_ACCUMULATE = 1u << 0, /* add to d_accum instead of overwriting it; the
+                                     8-bit image is then made from the running mean */
+    RT_FLAG_DIRECT_LIGHT = 1u << 1 /* CameraRenderProperties::enableLDirect: add
+                                      Camera::computeDirectLighting at every hit (one shadow
+                                      query per uploaded light); inert without lights */
 };
 
 /* Render request: CameraRenderProperties (inc/Camera.h:14-22) plus the frame
@@ -125,6 +142,10 @@ const char *rt_last_error(const rt_ctx *ctx);
  * Sphere order = insertion order = tie-break order.  mat_id[i] indexes mats[]. */
 int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_spheres,
                     const uint32_t *h_mat_id, int n_mats, const rt_material *h_mats);
+
+/* Replaces SceneManager's light list as read by Camera::computeDirectLighting
+ * (reference src/Camera.cpp:161-178, inc/RayTracer.h:26,30).  n_lights may be 0. */
+int rt_upload_lights(rt_ctx *ctx, int n_lights, const rt_light *h_lights);
 
 /* Replaces Camera::center()/viewPort() reads inside genRay (src/Camera.cpp:124-135). */
 int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);

@@ -15,8 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 SPHERE_DTYPE = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("r", "<f4")])
 MATERIAL_DTYPE = np.dtype(
-    [("type", "<u4"), ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4"), ("emission", "<f4", 3), ("_pad", "<f4")]
+    [("type", "<u4"), ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4"), ("emission", "<f4", 3), ("diffuse", "<f4", 3)]
 )
+LIGHT_DTYPE = np.dtype([("position", "<f4", 3), ("ambient", "<f4", 3), ("diffuse", "<f4", 3), ("specular", "<f4", 3),
+                        ("view_pow", "<f4"), ("_pad", "<f4", 3)])
 CAMERA_DTYPE = np.dtype([("center", "<f4", 3), ("upper_left", "<f4", 3), ("right", "<f4", 3), ("down", "<f4", 3)])
 
 
@@ -39,7 +41,7 @@ class Oracle:
         L = self.lib
         vp, i32, u32 = C.c_void_p, C.c_int, C.c_uint32
         L.orc_rng4.argtypes = [u32, u32, u32, u32, C.POINTER(u32)]
-        L.orc_render.argtypes = [i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, u32, i32, i32, i32, i32, vp, vp]
+        L.orc_render.argtypes = [i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, u32, i32, i32, i32, i32, vp, vp]
         L.orc_render.restype = C.c_uint64
         L.orc_first_hit.argtypes = [i32, vp, i32, vp, vp, C.c_double, vp, vp, vp, vp, vp]
         L.orc_scatter.argtypes = [i32] + [vp] * 11
@@ -66,11 +68,18 @@ class Oracle:
         return np.array(list(out), dtype=np.uint32)
 
     def render(self, scene, W, H, spp, max_depth, seed=0, samples_per_scatter=1, sample_offset=0,
-               iterative=False, y0=0, y1=None, want_accum=True):
+               iterative=False, y0=0, y1=None, want_accum=True, direct_light=False):
+        """direct_light=True renders with enableLDirect and the scene's lights."""
         sph, mid, mats, cam = self._scene_args(scene)
+        lights = getattr(scene, "lights", None)
+        if not direct_light or lights is None or len(lights) == 0:
+            lights, n_l = None, 0
+        else:
+            lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+            n_l = len(lights)
         rgba = np.zeros((H, W, 4), np.uint8)
         accum = np.zeros((H, W, 3), np.float64) if want_accum else None
-        rays = self.lib.orc_render(len(sph), _p(sph), _p(mid), len(mats), _p(mats), _p(cam), W, H, spp,
+        rays = self.lib.orc_render(len(sph), _p(sph), _p(mid), len(mats), _p(mats), n_l, _p(lights), _p(cam), W, H, spp,
                                    samples_per_scatter, max_depth, seed, sample_offset, 1 if iterative else 0,
                                    y0, H if y1 is None else y1, _p(rgba), _p(accum))
         return rgba, accum, int(rays)

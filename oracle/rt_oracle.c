@@ -48,8 +48,13 @@ typedef struct {
     float fuzz;
     float ior;
     float emission[3];
-    float _pad;
+    float diffuse[3];
 } orc_material;
+typedef struct {
+    float position[3], ambient[3], diffuse[3], specular[3];
+    float view_pow;
+    float _pad[3];
+} orc_light;
 typedef struct { float center[3], upper_left[3], right[3], down[3]; } orc_camera;
 
 enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_EMISSIVE = 3 };
@@ -62,6 +67,9 @@ typedef struct {
     const uint32_t *mat_id;
     int n_mats;
     const orc_material *mats;
+    int n_lights;             /* 0 unless direct lighting is enabled */
+    const orc_light *lights;
+    vec3 cam_center;          /* Camera::center_, read by computeDirectLighting */
 } scene_t;
 
 /* HitRecord, reference inc/RTGeometry.h:49-62 (material/object pointers become indices) */
@@ -258,6 +266,46 @@ static int scatter(const orc_material *m, vec3 in_dir, const hitrec *rec, const 
 
 static const real TMIN = (real)0.001; /* CLOSEST_HIT_MIN_T, reference src/Camera.cpp:10 */
 
+/* Light::getDirectLighting with defuseLightIntensity (Lambert) and specularLightIntesity
+ * (Phong), reference inc/RTObjects.h:247-257, 300-320.  getOrtogonal(a, b) is the part of a
+ * orthogonal to b, so toLight - 2*getOrtogonal(toLight, n) is toLight mirrored about n. */
+static vec3 light_direct(const orc_light *lt, vec3 to_view, const hitrec *rec, const orc_material *m, int hitted) {
+    vec3 to_light = vnormalized(vsub(vf(lt->position), rec->point));
+    vec3 mdiff = vf(m->diffuse);
+    vec3 ambient = vmul(vf(lt->ambient), mdiff);
+    real cos_l = vdot(vnormalized(to_light), vnormalized(rec->normal));
+    vec3 diffuse = cos_l > 0 ? vmul(vmuls(vf(lt->diffuse), cos_l), mdiff) : v3(0, 0, 0);
+    vec3 nn = rec->normal;
+    vec3 ortho = vsub(to_light, vmuls(nn, vdot(to_light, nn) / vdot(nn, nn)));
+    vec3 refl = vsub(to_light, vmuls(ortho, 2));
+    real cos_v = vdot(vnormalized(refl), vnormalized(vnormalized(to_view)));
+    vec3 specular = v3(0, 0, 0);
+    if (cos_v > 0) {
+        real k = (real)pow((double)cos_v, (double)lt->view_pow);
+        specular = v3(k, k, k);
+    }
+    real shadow = hitted ? (real)0.0 : (real)1.0;
+    return vadd(ambient, vmuls(vadd(diffuse, specular), shadow));
+}
+
+static int hit_closest(const scene_t *s, vec3 O, vec3 D, real tmin, real tmax, hitrec *rec);
+
+/* Camera::computeDirectLighting, reference src/Camera.cpp:161-178: one closest-hit query per light
+ * along the (unnormalised, unbounded) ray towards it; a hit on the shaded object itself does not count. */
+static vec3 direct_lighting(const scene_t *s, const hitrec *rec, const orc_material *m, uint64_t *rays) {
+    vec3 sum = v3(0, 0, 0);
+    vec3 to_view = vsub(s->cam_center, rec->point);
+    for (int i = 0; i < s->n_lights; i++) {
+        const orc_light *lt = &s->lights[i];
+        hitrec tmp;
+        (*rays)++;
+        int hitted = hit_closest(s, rec->point, vsub(vf(lt->position), rec->point), (real)0.001, (real)INFINITY, &tmp);
+        if (hitted && tmp.object == rec->object) hitted = 0;
+        sum = vadd(sum, light_direct(lt, to_view, rec, m, hitted));
+    }
+    return sum;
+}
+
 typedef struct {
     const scene_t *s;
     int samples_per_scatter;
@@ -271,7 +319,7 @@ static vec3 sky(vec3 d) {
 }
 
 /* Camera::getRayColor + computeMultipleScatterLInderect, reference src/Camera.cpp:137-157,180-195,
- * recursive exactly as written (enableLDirect off / no lights: the :150 term is zero). */
+ * recursive exactly as written (the :150 term is direct_lighting when lights are enabled). */
 static vec3 ray_color(trace_ctx *tc, rng_t *g, vec3 O, vec3 D, int depth) {
     if (depth == 0) return v3(0, 0, 0);
     hitrec rec;
@@ -288,7 +336,8 @@ static vec3 ray_color(trace_ctx *tc, rng_t *g, vec3 O, vec3 D, int depth) {
                 lind = vadd(lind, vmul(att, ray_color(tc, g, so, sd, depth - 1)));
         }
         lind = vmuls(lind, (real)1.0 / (real)tc->samples_per_scatter);
-        return vadd(vadd(emitted, lind), v3(0, 0, 0));
+        vec3 ldirect = tc->s->n_lights ? direct_lighting(tc->s, &rec, m, &tc->rays) : v3(0, 0, 0);
+        return vadd(vadd(emitted, lind), ldirect);
     }
     return sky(D);
 }
@@ -306,6 +355,7 @@ static vec3 ray_color_iter(trace_ctx *tc, rng_t *g, vec3 O, vec3 D, int max_dept
         }
         const orc_material *m = &tc->s->mats[tc->s->mat_id[rec.object]];
         L = vadd(L, vmul(T, vf(m->emission)));
+        if (tc->s->n_lights) L = vadd(L, vmul(T, direct_lighting(tc->s, &rec, m, &tc->rays)));
         real u[4];
         rng_next(g, u);
         vec3 att, so, sd;
@@ -346,14 +396,16 @@ ORC_API void orc_convert_color(const double rgb[3], uint8_t out[4]) {
 /* Camera::renderParallel + renderPixelColor, reference src/Camera.cpp:69-88,105-122.
  * gm::setThreadSeed(pixelId) (:84) becomes "the stream is keyed on pixelId".
  *   iterative != 0 selects ray_color_iter (requires samples_per_scatter == 1).
+ *   n_lights > 0 enables Camera::computeDirectLighting (enableLDirect) with those lights.
  *   rows [y0, y1) are rendered; rgba/accum are full W*H buffers (accum: W*H*3 doubles,
  *   per-pixel sample SUM; may be NULL).  sample_offset shifts the sample index.
  * Returns the number of hitClosest calls. */
 ORC_API uint64_t orc_render(int n, const orc_sphere *sph, const uint32_t *mat_id, int n_mats,
-                            const orc_material *mats, const orc_camera *cam, int W, int H, int spp,
+                            const orc_material *mats, int n_lights, const orc_light *lights,
+                            const orc_camera *cam, int W, int H, int spp,
                             int samples_per_scatter, int max_depth, uint32_t seed, int sample_offset,
                             int iterative, int y0, int y1, uint8_t *rgba, double *accum) {
-    scene_t s = {n, sph, mat_id, n_mats, mats};
+    scene_t s = {n, sph, mat_id, n_mats, mats, n_lights, lights, vf(cam->center)};
     uint64_t total = 0;
     if (y0 < 0) y0 = 0;
     if (y1 > H) y1 = H;
@@ -398,7 +450,7 @@ ORC_API uint64_t orc_render(int n, const orc_sphere *sph, const uint32_t *mat_id
 ORC_API void orc_first_hit(int n, const orc_sphere *sph, int n_rays, const float *org, const float *dir,
                            double tmin, int32_t *id, double *t, double *normal, uint8_t *front,
                            double *margin) {
-    scene_t s = {n, sph, NULL, 0, NULL};
+    scene_t s = {n, sph, NULL, 0, NULL, 0, NULL, {0, 0, 0}};
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n_rays; i++) {
         vec3 O = vf(org + 3 * i), D = vf(dir + 3 * i);
@@ -473,7 +525,7 @@ ORC_API void orc_sample_radiance(int n, const orc_sphere *sph, const uint32_t *m
                                  const orc_material *mats, const orc_camera *cam, int W, int H, int pid,
                                  int smp, int samples_per_scatter, int max_depth, uint32_t seed,
                                  int iterative, double out[3]) {
-    scene_t s = {n, sph, mat_id, n_mats, mats};
+    scene_t s = {n, sph, mat_id, n_mats, mats, 0, NULL, vf(cam->center)};
     trace_ctx tc = {&s, samples_per_scatter, 0};
     rng_t g = {(uint32_t)pid, (uint32_t)smp, 0, seed};
     real u[4];

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  
 
 STRIP_ROWS = 8
 FLAG_ACCUMULATE = 1
+FLAG_DIRECT_LIGHT = 2
 FH_REFINE = 1
 
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
@@ -23,10 +24,13 @@ MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
 # numpy views of the ABI structs
 SPHERE_DTYPE = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("r", "<f4")])
 MATERIAL_DTYPE = np.dtype(
-    [("type", "<u4"), ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4"), ("emission", "<f4", 3), ("_pad", "<f4")]
+    [("type", "<u4"), ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4"), ("emission", "<f4", 3), ("diffuse", "<f4", 3)]
 )
+LIGHT_DTYPE = np.dtype([("position", "<f4", 3), ("ambient", "<f4", 3), ("diffuse", "<f4", 3), ("specular", "<f4", 3),
+                        ("view_pow", "<f4"), ("_pad", "<f4", 3)])
 CAMERA_DTYPE = np.dtype([("center", "<f4", 3), ("upper_left", "<f4", 3), ("right", "<f4", 3), ("down", "<f4", 3)])
-assert SPHERE_DTYPE.itemsize == 16 and MATERIAL_DTYPE.itemsize == 40 and CAMERA_DTYPE.itemsize == 48
+assert SPHERE_DTYPE.itemsize == 16 and MATERIAL_DTYPE.itemsize == 48 and CAMERA_DTYPE.itemsize == 48
+assert LIGHT_DTYPE.itemsize == 64
 
 
 class RtError(RuntimeError):
@@ -70,7 +74,7 @@ class RenderParams:
 
 EXPORTS = [
     "rt_version", "rt_rng4", "rt_output_rows", "rt_create", "rt_destroy", "rt_last_error",
-    "rt_upload_scene", "rt_set_camera", "rt_render", "rt_render_host", "rt_first_hit",
+    "rt_upload_scene", "rt_upload_lights", "rt_set_camera", "rt_render", "rt_render_host", "rt_first_hit",
     "rt_first_hit_host", "rt_scatter_host",
 ]
 
@@ -102,6 +106,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_upload_scene.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     lib.rt_upload_scene.restype = C.c_int
+    lib.rt_upload_lights.argtypes = [vp, C.c_int, vp]
+    lib.rt_upload_lights.restype = C.c_int
     lib.rt_set_camera.argtypes = [vp, vp]
     lib.rt_set_camera.restype = C.c_int
     lib.rt_render.argtypes = [vp, C.POINTER(_Params), vp, vp, vp, vp]
@@ -183,6 +189,11 @@ class Renderer:
         )
         self.n_spheres = len(spheres)
 
+    def upload_lights(self, lights: np.ndarray | None):
+        n = 0 if lights is None else len(lights)
+        arr = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE) if n else None
+        self._check(self.lib.rt_upload_lights(self.h, n, _ptr(arr) if n else None), "rt_upload_lights")
+
     def set_camera(self, cam: np.ndarray):
         cam = np.ascontiguousarray(cam, dtype=CAMERA_DTYPE).reshape(1)
         self._check(self.lib.rt_set_camera(self.h, _ptr(cam)), "rt_set_camera")
@@ -190,6 +201,7 @@ class Renderer:
     def set_scene(self, scene):
         """scene: a scenes.Scene"""
         self.upload_scene(scene.spheres, scene.mat_id, scene.mats)
+        self.upload_lights(getattr(scene, "lights", None))
         self.set_camera(scene.camera)
 
     # -- render ---------------------------------------------------------------

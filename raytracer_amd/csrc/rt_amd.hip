@@ -51,6 +51,7 @@ struct KParams {
     int tiles_per_strip; // tiles_x * (8 / tile height)
     int n_items;         // tiles this call renders
     int n_quads;     // sphere quads to scan (padding included)
+    int n_lights;    // lights shaded at every hit (0 unless RT_FLAG_DIRECT_LIGHT)
     float inv_w, inv_h;
     float cam[12];   // center, upper_left, right, down
 };
@@ -61,6 +62,7 @@ struct DeviceScene {
                           // never-hit spheres to a multiple of 8 plus four spare quads
     const uint32_t *mat_id;
     const DMat *mats;
+    const DLight *lights;
 };
 
 // Where the scan loop takes the sphere words from.
@@ -159,6 +161,17 @@ struct Path {
     int self_id;  // sphere whose surface the ray starts on exactly (diffuse / metal bounce), else -1
 };
 
+// Extra per-path state of the direct-lighting variant: while the shadow queries of a hit run, the
+// lane's ray registers hold the shadow ray and the already-scattered bounce waits here.
+struct LightState {
+    int light_i;   // -1: the lane traces its path ray; k >= 0: the shadow ray towards light k
+    V3 hp, hn;     // the shaded hit (HitRecord::point / normal)
+    int hobj, hmat; // its object and material index
+    V3 nxt_o, nxt_d, att; // the bounce to resume with
+    int nxt_self;
+    bool nxt_valid; // false: the path ends after the shadow queries
+};
+
 // Per-ray setup of the scan: unit direction, its length, and the packed operands.
 __device__ __forceinline__ void set_dir(Path &pt, V3 d) {
     pt.d = d;
@@ -196,7 +209,7 @@ __device__ __forceinline__ Tile decode_item(const KParams &p, unsigned item) {
 // items from one global counter until it runs dry, so the grid stays busy however
 // uneven the image is.  Inside an item the wave runs the path loop described at the
 // top of this file.
-template <int SRC>
+template <int SRC, bool LIGHTS>
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
@@ -228,6 +241,13 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
     pt.self_id = -1;
     unsigned long long my_rays = 0;
     bool need_work = false;
+    LightState ls;
+    ls.light_i = -1;
+    ls.hp = ls.hn = ls.nxt_o = ls.nxt_d = ls.att = mk(0, 0, 0);
+    ls.hobj = ls.hmat = 0;
+    ls.nxt_self = -1;
+    ls.nxt_valid = false;
+    const V3 cam_center = mk(p.cam[0], p.cam[1], p.cam[2]);
 
     // wave-uniform item state
     bool have_item = false, queue_empty = false;
@@ -267,9 +287,10 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
             if (!have_item) break;
         }
 
-        const bool active = pt.pix >= 0 && pt.depth > 0;
+        const bool in_shadow = LIGHTS && ls.light_i >= 0;
+        const bool active = pt.pix >= 0 && (pt.depth > 0 || in_shadow);
         // a path with no depth left (max_depth == 0) contributes black and ends at once
-        bool finished = pt.pix >= 0 && pt.depth <= 0;
+        bool finished = pt.pix >= 0 && pt.depth <= 0 && !in_shadow;
 
         // ---- closest hit over all spheres (SceneManager::hitClosest, src/RayTracer.cpp:77-82) ----
         float best_t = __builtin_inff(); // in units of |d|
@@ -297,24 +318,59 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
         h.front = false;
         float4 at = make_float4(0, 0, 0, 0), ef = make_float4(0, 0, 0, 0);
         float ior = 1.f;
+        int hit_mat = 0;
+        const bool shadow_ray = LIGHTS && ls.light_i >= 0;
         if (active) {
             my_rays++;
-            pt.depth--;
             if (pt.self_id >= 0) self_hit(pt.o, pt.dh, tmin, sc.sph[pt.self_id], pt.self_id, best_t, best_id);
-            if (best_id < 0) {
-                pt.L = pt.L + pt.T * sky(pt.d);
-                finished = true;
+            if (!shadow_ray) {
+                pt.depth--;
+                if (best_id < 0) {
+                    pt.L = pt.L + pt.T * sky(pt.d);
+                    finished = true;
+                } else {
+                    h = finish_hit(pt.o, pt.d, best_t * pt.inv_len, sc.sph[best_id]);
+                    hit_mat = (int)sc.mat_id[best_id];
+                    const DMat &m = sc.mats[hit_mat];
+                    at = m.albedo_type;
+                    ef = m.emission_fuzz;
+                    ior = m.ior_diffuse.x;
+                    pt.L = pt.L + pt.T * mk(ef.x, ef.y, ef.z);
+                    // an emissive surface ends the path (RTEmissive::scatter, inc/RTMaterial.h:205-207); so does
+                    // running out of depth: the next getRayColor would return black (src/Camera.cpp:138)
+                    if (__float_as_uint(at.w) == 3u || pt.depth == 0) finished = true;
+                    else bounce = true;
+                    if (LIGHTS && p.n_lights > 0) {
+                        // Camera::computeDirectLighting (src/Camera.cpp:161-178): the hit is kept, the shadow
+                        // queries run in the following iterations, then the path resumes or ends
+                        ls.hp = h.p;
+                        ls.hn = h.n;
+                        ls.hobj = best_id;
+                        ls.hmat = hit_mat;
+                        ls.nxt_valid = bounce;
+                        ls.light_i = 0;
+                        finished = false;
+                    }
+                }
             } else {
-                h = finish_hit(pt.o, pt.d, best_t * pt.inv_len, sc.sph[best_id]);
-                const DMat &m = sc.mats[sc.mat_id[best_id]];
-                at = m.albedo_type;
-                ef = m.emission_fuzz;
-                ior = m.ior_pad.x;
-                pt.L = pt.L + pt.T * mk(ef.x, ef.y, ef.z);
-                // an emissive surface ends the path (RTEmissive::scatter, inc/RTMaterial.h:205-207); so does
-                // running out of depth: the next getRayColor would return black (src/Camera.cpp:138)
-                if (__float_as_uint(at.w) == 3u || pt.depth == 0) finished = true;
-                else bounce = true;
+                // the closest hit along the ray towards the light; a hit on the shaded object itself does
+                // not count (src/Camera.cpp:169-172)
+                const bool hitted = best_id >= 0 && best_id != ls.hobj;
+                float4 idf = sc.mats[ls.hmat].ior_diffuse;
+                pt.L = pt.L + pt.T * light_direct(sc.lights[ls.light_i], cam_center, ls.hp, ls.hn,
+                                                  mk(idf.y, idf.z, idf.w), hitted);
+                ls.light_i++;
+                if (ls.light_i >= p.n_lights) {
+                    ls.light_i = -1;
+                    if (ls.nxt_valid) {
+                        pt.T = pt.T * ls.att;
+                        pt.o = ls.nxt_o;
+                        set_dir(pt, ls.nxt_d);
+                        pt.self_id = ls.nxt_self;
+                    } else {
+                        finished = true;
+                    }
+                }
             }
         }
         if (finished) {
@@ -375,16 +431,34 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
             V3 nd;
             if (fresh) {
                 gen_ray(p, px, py, u01(w0), u01(w1), pt.o, nd);
+                if (LIGHTS) ls.light_i = -1;
+                set_dir(pt, nd);
             } else {
                 V3 att, no;
                 scatter(__float_as_uint(at.w), mk(at.x, at.y, at.z), ef.w, ior, pt.d, h, u01(w0), u01(w1), u01(w2), att,
                         no, nd);
-                pt.T = pt.T * att;
-                pt.o = no;
                 // diffuse and metal bounces start exactly on the sphere; the dielectric nudges its origin
-                pt.self_id = __float_as_uint(at.w) <= 1u ? best_id : -1;
+                const int nself = __float_as_uint(at.w) <= 1u ? best_id : -1;
+                if (LIGHTS && p.n_lights > 0) {
+                    ls.nxt_o = no;
+                    ls.nxt_d = nd;
+                    ls.att = att;
+                    ls.nxt_self = nself;
+                } else {
+                    pt.T = pt.T * att;
+                    pt.o = no;
+                    pt.self_id = nself;
+                    set_dir(pt, nd);
+                }
             }
-            set_dir(pt, nd);
+        }
+        if (LIGHTS && ls.light_i >= 0 && pt.pix >= 0) {
+            // (next) shadow ray: from the hit point towards the light, direction unnormalised as in
+            // the reference (src/Camera.cpp:166)
+            float4 lp = sc.lights[ls.light_i].pos_pow;
+            pt.o = ls.hp;
+            set_dir(pt, mk(lp.x, lp.y, lp.z) - ls.hp);
+            pt.self_id = ls.hobj;
         }
 
         // ---- tile done: tone-map and store (convertRTColor, src/Camera.cpp:19-34) ----
@@ -574,7 +648,7 @@ __global__ void scatter_kernel(int n, const DMat *__restrict__ mats, const uint3
     h.n = mk(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
     h.front = front[i] != 0;
     V3 a = mk(0, 0, 0), o = mk(0, 0, 0), d = mk(0, 0, 0);
-    bool ok = scatter(__float_as_uint(at.w), mk(at.x, at.y, at.z), ef.w, m.ior_pad.x,
+    bool ok = scatter(__float_as_uint(at.w), mk(at.x, at.y, at.z), ef.w, m.ior_diffuse.x,
                       mk(in_dir[3 * i], in_dir[3 * i + 1], in_dir[3 * i + 2]), h, u[3 * i], u[3 * i + 1], u[3 * i + 2],
                       a, o, d);
     flag[i] = ok ? 1 : 0;
@@ -599,8 +673,11 @@ struct rt_ctx {
     unsigned *d_queue = nullptr; // work-item counter of the persistent render kernel (256 B, zeroed per launch)
     int n_cus = 256;
     int wgs_per_cu = 8;
+    int force_tile = -1; // tuning: 0 = 32x8, 1 = 8x8, 2 = 4x4 work-item tiles
     uint32_t *d_mat_id = nullptr;
     DMat *d_mats = nullptr;
+    DLight *d_lights = nullptr;
+    int n_lights = 0;
     int n_spheres = 0;
     int n_mats = 0;
     bool have_scene = false;
@@ -659,7 +736,7 @@ int local_strips(const rt_params *p) {
 
 } // namespace
 
-RT_API int rt_version(void) { return 100; }
+RT_API int rt_version(void) { return 101; }
 
 RT_API void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint32_t out[4]) {
     rng4(pixel, sample, call, seed, out[0], out[1], out[2], out[3]);
@@ -686,9 +763,13 @@ RT_API int rt_create(int device, rt_ctx **out) {
     }
     // allow the render kernels their dynamic LDS budget
     size_t lds_max = ACC_BYTES + (size_t)RESIDENT_MAX * sizeof(float4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_RESIDENT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_RESIDENT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_STREAMED>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_STREAMED, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_RESIDENT, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_STREAMED, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -700,6 +781,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
     if (const char *w = getenv("RT_AMD_WGS_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 64) ctx->wgs_per_cu = v; }
     // where the scan takes sphere data from: scalar loads (default, fastest measured) or LDS
     // broadcast reads ("lds": resident copy for small scenes, streamed tiles for large ones)
+    if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (v >= 0 && v <= 4) ctx->force_tile = v; }
     const char *src = getenv("RT_AMD_SPHERE_SOURCE");
     ctx->scalar_source = !(src && strcmp(src, "lds") == 0);
     *out = ctx;
@@ -710,6 +792,7 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     free_scene(ctx);
+    if (ctx->d_lights) (void)hipFree(ctx->d_lights);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     delete ctx;
 }
@@ -764,7 +847,7 @@ RT_API int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_sphere
             memcpy(&tbits, &ty, 4);
             m.albedo_type = make_float4(h.albedo[0], h.albedo[1], h.albedo[2], tbits);
             m.emission_fuzz = make_float4(h.emission[0], h.emission[1], h.emission[2], h.fuzz);
-            m.ior_pad = make_float4(h.ior, 0, 0, 0);
+            m.ior_diffuse = make_float4(h.ior, h.diffuse[0], h.diffuse[1], h.diffuse[2]);
         }
         mats[i] = m;
     }
@@ -780,6 +863,27 @@ RT_API int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_sphere
     ctx->n_quads = n_quads;
     ctx->n_mats = n_mats;
     ctx->have_scene = true;
+    return RT_OK;
+}
+
+RT_API int rt_upload_lights(rt_ctx *ctx, int n_lights, const rt_light *h_lights) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (n_lights < 0 || (n_lights > 0 && !h_lights)) return fail(ctx, RT_ERR_INVALID, "bad light array");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->d_lights) (void)hipFree(ctx->d_lights);
+    ctx->d_lights = nullptr;
+    ctx->n_lights = 0;
+    if (n_lights == 0) return RT_OK;
+    std::vector<DLight> l((size_t)n_lights);
+    for (int i = 0; i < n_lights; ++i) {
+        const rt_light &h = h_lights[i];
+        l[i].pos_pow = make_float4(h.position[0], h.position[1], h.position[2], h.view_pow);
+        l[i].ambient = make_float4(h.ambient[0], h.ambient[1], h.ambient[2], 0);
+        l[i].diffuse = make_float4(h.diffuse[0], h.diffuse[1], h.diffuse[2], 0);
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_lights, l.size() * sizeof(DLight)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_lights, l.data(), l.size() * sizeof(DLight), hipMemcpyHostToDevice));
+    ctx->n_lights = n_lights;
     return RT_OK;
 }
 
@@ -815,7 +919,7 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     int nstrips = local_strips(p);
     if (nstrips == 0) return RT_OK;
     {
-        static const int shapes[3][2] = {{5, 3}, {3, 3}, {2, 2}}; // 32x8, 8x8, 4x4 (log2 w, log2 h)
+        static const int shapes[5][2] = {{5, 3}, {3, 3}, {2, 2}, {1, 1}, {0, 0}}; // 32x8, 8x8, 4x4, 2x2, 1x1 (log2)
         const int spp = p->samples_per_pixel;
         int pick = spp >= 256 ? 2 : (spp >= 64 ? 1 : 0);
         auto items_of = [&](int i) {
@@ -826,6 +930,7 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
         while (pick < 2 && items_of(pick) < enough &&
                (long long)spp << (shapes[pick + 1][0] + shapes[pick + 1][1]) >= 256)
             ++pick;
+        if (ctx->force_tile >= 0) pick = ctx->force_tile;
         k.tile_w_log2 = shapes[pick][0];
         k.tile_h_log2 = shapes[pick][1];
     }
@@ -833,13 +938,14 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     k.tiles_x = (p->width + tw - 1) / tw;
     k.tiles_per_strip = k.tiles_x * (RT_STRIP_ROWS / th);
     k.n_quads = ctx->n_quads;
+    k.n_lights = (p->flags & RT_FLAG_DIRECT_LIGHT) ? ctx->n_lights : 0;
     k.inv_w = 1.0f / (float)p->width;
     k.inv_h = 1.0f / (float)p->height;
     memcpy(k.cam + 0, ctx->cam.center, 12);
     memcpy(k.cam + 3, ctx->cam.upper_left, 12);
     memcpy(k.cam + 6, ctx->cam.right, 12);
     memcpy(k.cam + 9, ctx->cam.down, 12);
-    DeviceScene sc{ctx->d_sph, ctx->d_pairs, ctx->d_mat_id, ctx->d_mats};
+    DeviceScene sc{ctx->d_sph, ctx->d_pairs, ctx->d_mat_id, ctx->d_mats, ctx->d_lights};
     long long items = (long long)nstrips * k.tiles_per_strip;
     if (items > 0x7fffffffLL) return fail(ctx, RT_ERR_INVALID, "too many tiles for one call");
     k.n_items = (int)items;
@@ -853,18 +959,20 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     float4 *o_acc = (float4 *)d_accum;
     unsigned long long *o_rays = (unsigned long long *)d_rays;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 256, st));
-    if (ctx->scalar_source) {
-        hipLaunchKernelGGL(render_kernel<SRC_SCALAR>, grid, block, ACC_BYTES, st, k, sc, o_rgba, o_acc, o_rays,
-                           ctx->d_queue);
-    } else if (ctx->n_quads * 4 <= RESIDENT_MAX) {
-        size_t lds = ACC_BYTES + (size_t)(ctx->n_quads > 0 ? ctx->n_quads : 1) * 4 * sizeof(float4);
-        hipLaunchKernelGGL(render_kernel<SRC_LDS_RESIDENT>, grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays,
-                           ctx->d_queue);
-    } else {
-        size_t lds = ACC_BYTES + (size_t)STREAM_QUADS * 4 * sizeof(float4);
-        hipLaunchKernelGGL(render_kernel<SRC_LDS_STREAMED>, grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays,
-                           ctx->d_queue);
+    const bool lights = k.n_lights > 0;
+    size_t lds = ACC_BYTES;
+    int src = SRC_SCALAR;
+    if (!ctx->scalar_source) {
+        const bool resident = ctx->n_quads * 4 <= RESIDENT_MAX;
+        src = resident ? SRC_LDS_RESIDENT : SRC_LDS_STREAMED;
+        lds += (size_t)(resident ? (ctx->n_quads > 0 ? ctx->n_quads : 1) : STREAM_QUADS) * 4 * sizeof(float4);
     }
+#define RT_LAUNCH(S, L)                                                                                   \
+    hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays, ctx->d_queue)
+    if (src == SRC_SCALAR) { if (lights) RT_LAUNCH(SRC_SCALAR, true); else RT_LAUNCH(SRC_SCALAR, false); }
+    else if (src == SRC_LDS_RESIDENT) { if (lights) RT_LAUNCH(SRC_LDS_RESIDENT, true); else RT_LAUNCH(SRC_LDS_RESIDENT, false); }
+    else { if (lights) RT_LAUNCH(SRC_LDS_STREAMED, true); else RT_LAUNCH(SRC_LDS_STREAMED, false); }
+#undef RT_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -915,7 +1023,7 @@ RT_API int rt_first_hit(rt_ctx *ctx, int n_rays, const float *d_org, const float
     if (n_rays == 0) return RT_OK;
     if (!d_org || !d_dir || !d_id) return fail(ctx, RT_ERR_INVALID, "null ray/id array");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DeviceScene sc{ctx->d_sph, ctx->d_pairs, ctx->d_mat_id, ctx->d_mats};
+    DeviceScene sc{ctx->d_sph, ctx->d_pairs, ctx->d_mat_id, ctx->d_mats, ctx->d_lights};
     dim3 grid((unsigned)((n_rays + WG_THREADS - 1) / WG_THREADS)), block(WG_THREADS);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (flags & RT_FH_REFINE)

@@ -27,7 +27,14 @@ __device__ __forceinline__ V3 normalized(V3 a) { return a * __frsqrt_rn(dot(a, a
 struct DMat {
     float4 albedo_type; // albedo rgb, type in the bits of .w
     float4 emission_fuzz; // emission rgb, fuzz
-    float4 ior_pad;       // ior, unused
+    float4 ior_diffuse;   // ior, RTMaterial::diffuse_ rgb (read by direct lighting only)
+};
+
+// Device copy of one Phong point light (class Light, inc/RTObjects.h:220-226).
+struct DLight {
+    float4 pos_pow;  // position, viewLightPow_
+    float4 ambient;  // ambientIntensity_
+    float4 diffuse;  // defuseIntensity_
 };
 
 // ---- random numbers ------------------------------------------------------
@@ -234,6 +241,26 @@ __device__ __forceinline__ bool scatter(uint32_t type, V3 albedo, float fuzz, fl
         return true;
     }
     return false; // Emissive
+}
+
+// Light::getDirectLighting with its Lambert and Phong terms (inc/RTObjects.h:247-257, 300-320):
+// ambient*diffuse_ + (max(0, cos)*defuse*diffuse_ + pow(max(0, cos(mirror(toLight), toView)), pow)) * shadow.
+// toLight - 2*getOrtogonal(toLight, n) is toLight mirrored about the (unit) normal.
+__device__ __forceinline__ V3 light_direct(const DLight &lt, V3 cam_center, V3 p, V3 n, V3 mdiff, bool hitted) {
+    V3 to_light = normalized(mk(lt.pos_pow.x, lt.pos_pow.y, lt.pos_pow.z) - p);
+    V3 to_view = normalized(cam_center - p);
+    V3 out = mk(lt.ambient.x, lt.ambient.y, lt.ambient.z) * mdiff;
+    if (!hitted) {
+        float cos_l = dot(to_light, n);
+        if (cos_l > 0.0f) out = out + mk(lt.diffuse.x, lt.diffuse.y, lt.diffuse.z) * mdiff * cos_l;
+        V3 refl = madd(to_light * -1.0f, n, 2.0f * cos_l);
+        float cos_v = dot(normalized(refl), to_view);
+        if (cos_v > 0.0f) {
+            float k = powf(cos_v, lt.pos_pow.w);
+            out = out + mk(k, k, k);
+        }
+    }
+    return out;
 }
 
 // sky colour on a miss, src/Camera.cpp:155-156 (direction used un-normalised)

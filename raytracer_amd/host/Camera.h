@@ -43,7 +43,7 @@ struct Viewport {
 };
 
 // Thrown by Camera::render when the scene uses something outside the accelerated path
-// (selected objects, lights with enableLDirect, a non-sphere primitive) or a HIP call fails.
+// (selected objects, a non-sphere primitive) or a HIP call fails.
 // The reference itself only asserts (src/Camera.cpp:76).
 class BackendError : public std::runtime_error {
 public:

@@ -1,8 +1,8 @@
 // RTObjects.h — host-side primitives with the reference's names
 // (reference inc/RTObjects.h:24-83 Primitives, :85-160 SphereObject, :220-321 Light).
 // hit() runs on the GPU.  Only the sphere is inside the accelerated path; scenes holding
-// anything the path does not cover (selected objects, lights with enableLDirect) are
-// rejected by Camera::render instead of being rendered differently from the reference.
+// anything the path does not cover (selected objects) are rejected by Camera::render
+// instead of being rendered differently from the reference.
 #ifndef RTAMD_RTOBJECTS_H
 #define RTAMD_RTOBJECTS_H
 
@@ -58,8 +58,8 @@ public:
     std::string typeString() const override { return "Sphere"; }
 };
 
-// Phong point light (reference inc/RTObjects.h:220-257).  Kept so that scenes holding lights can be
-// built; rendering with enableLDirect and a non-empty light list is outside the accelerated path.
+// Phong point light (reference inc/RTObjects.h:220-257).  getDirectLighting (:247-257, :300-320) runs on
+// the GPU; the const getters below are what the flattener reads (the reference keeps the fields private).
 class Light {
     gm::IVec3f ambientIntensity_, defuseIntensity_, specularIntensity_;
     gm::IPoint3 position_;
@@ -78,6 +78,11 @@ public:
     const SceneManager *parent() const { return parent_; }
     void setParent(const SceneManager *parent) { parent_ = parent; }
     virtual std::string typeString() const { return "Light"; }
+
+    const gm::IVec3f &ambientIntensity() const { return ambientIntensity_; }
+    const gm::IVec3f &defuseIntensity() const { return defuseIntensity_; }
+    const gm::IVec3f &specularIntensity() const { return specularIntensity_; }
+    double viewLightPow() const { return viewLightPow_; }
 };
 
 } // namespace rtamd

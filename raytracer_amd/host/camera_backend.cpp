@@ -78,9 +78,6 @@ void Camera::render(const SceneManager &sceneManager, const std::pair<int, int> 
     // the reference asserts this (src/Camera.cpp:76); a short buffer cannot be rendered into
     if ((size_t)W * (size_t)H != outputBufer.size())
         throw BackendError(RT_ERR_INVALID, "Camera::render: outputBufer.size() != width*height");
-    if (renderProperties.enableLDirect && !sceneManager.lights().empty())
-        throw BackendError(RT_ERR_UNSUPPORTED,
-                           "Camera::render: direct lighting (enableLDirect with lights) is outside the GPU path");
 
     // ---- flatten: spheres in insertion order, materials de-duplicated by pointer ----
     std::vector<rt_sphere> spheres;
@@ -114,6 +111,7 @@ void Camera::render(const SceneManager &sceneManager, const std::pair<int, int> 
             }
             put3(fm.albedo, albedo);
             put3(fm.emission, m->emitted());
+            put3(fm.diffuse, m->diffuse()); // what Light::getDirectLighting multiplies by
             it = seen.emplace(m, (uint32_t)mats.size()).first;
             mats.push_back(fm);
         }
@@ -132,6 +130,22 @@ void Camera::render(const SceneManager &sceneManager, const std::pair<int, int> 
     int rc = rt_upload_scene(ctx_, (int)spheres.size(), spheres.data(), matId.data(), (int)mats.size(), mats.data());
     if (rc != RT_OK) fail(ctx_, rc, "rt_upload_scene");
 
+    // lights feed Camera::computeDirectLighting (reference src/Camera.cpp:161-178) when enableLDirect is set
+    std::vector<rt_light> lights;
+    if (renderProperties.enableLDirect) {
+        for (const Light *l : sceneManager.lights()) {
+            rt_light fl{};
+            put3(fl.position, l->position());
+            put3(fl.ambient, l->ambientIntensity());
+            put3(fl.diffuse, l->defuseIntensity());
+            put3(fl.specular, l->specularIntensity());
+            fl.view_pow = (float)l->viewLightPow();
+            lights.push_back(fl);
+        }
+    }
+    rc = rt_upload_lights(ctx_, (int)lights.size(), lights.data());
+    if (rc != RT_OK) fail(ctx_, rc, "rt_upload_lights");
+
     rt_camera cam{};
     put3(cam.center, center_);
     put3(cam.upper_left, viewPort_.upperLeft_);
@@ -147,6 +161,7 @@ void Camera::render(const SceneManager &sceneManager, const std::pair<int, int> 
     p.samples_per_pixel = renderProperties.samplesPerPixel * sps;
     p.max_depth = renderProperties.maxRayDepth;
     p.seed = seed;
+    p.flags = lights.empty() ? 0u : (uint32_t)RT_FLAG_DIRECT_LIGHT;
     p.strip_first = 0;
     p.strip_stride = 1;
     static_assert(sizeof(RTPixelColor) == 4, "RTPixelColor must be 4 bytes of RGBA");

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .api import CAMERA_DTYPE, MATERIAL_DTYPE, SPHERE_DTYPE, MAT_DIELECTRIC, MAT_EMISSIVE, MAT_LAMBERTIAN, MAT_METAL
+from .api import CAMERA_DTYPE, LIGHT_DTYPE, MATERIAL_DTYPE, SPHERE_DTYPE, MAT_DIELECTRIC, MAT_EMISSIVE, MAT_LAMBERTIAN, MAT_METAL
 
 
 @dataclass
@@ -24,6 +24,7 @@ class Scene:
     mat_id: np.ndarray  # uint32 [n]
     mats: np.ndarray  # MATERIAL_DTYPE [m]
     camera: np.ndarray  # CAMERA_DTYPE [1]
+    lights: np.ndarray = None  # LIGHT_DTYPE [l] (Phong point lights; used with direct lighting only)
 
     @property
     def n_spheres(self) -> int:
@@ -56,6 +57,10 @@ class _Builder:
         self.sph = []
         self.mid = []
         self.mats = []
+        self.lights = []
+
+    def light(self, position, ambient, diffuse, specular, view_pow):
+        self.lights.append((tuple(position), tuple(ambient), tuple(diffuse), tuple(specular), float(view_pow)))
 
     def mat(self, type_, albedo=(0, 0, 0), fuzz=0.0, ior=1.0, emission=(0, 0, 0)) -> int:
         self.mats.append((type_, tuple(albedo), min(float(fuzz), 1.0), float(ior), tuple(emission)))
@@ -86,10 +91,19 @@ class _Builder:
             mats[i]["fuzz"] = f
             mats[i]["ior"] = ior
             mats[i]["emission"] = e
-        return Scene(name, spheres, np.array(self.mid, dtype=np.uint32), mats, camera)
+            # RTMaterial::diffuse_ is set by RTLambertian's constructor only (reference inc/RTMaterial.h:65)
+            mats[i]["diffuse"] = a if t == MAT_LAMBERTIAN else (0, 0, 0)
+        lights = np.zeros(len(self.lights), dtype=LIGHT_DTYPE)
+        for i, (pos, amb, dif, spec, vp) in enumerate(self.lights):
+            lights[i]["position"] = pos
+            lights[i]["ambient"] = amb
+            lights[i]["diffuse"] = dif
+            lights[i]["specular"] = spec
+            lights[i]["view_pow"] = vp
+        return Scene(name, spheres, np.array(self.mid, dtype=np.uint32), mats, camera, lights)
 
 
-def small_scene(bubble: bool = False, light: bool = False) -> Scene:
+def small_scene(bubble: bool = False, light: bool = False, phong: int = 0) -> Scene:
     """Ground + diffuse / metal / glass spheres in front of the default camera
     (centre 0, direction +z, so world-up falls back to +y)."""
     b = _Builder()
@@ -105,6 +119,10 @@ def small_scene(bubble: bool = False, light: bool = False) -> Scene:
         b.sphere((1.0, 0.0, 3.0), -0.4, right)
     if light:
         b.sphere((0.0, 1.5, 3.0), 0.4, b.emissive((4.0, 4.0, 4.0)))
+    if phong >= 1:  # Phong point lights (class Light, reference inc/RTObjects.h:220-321)
+        b.light((2.0, 3.0, 1.0), (0.05, 0.05, 0.05), (0.6, 0.6, 0.5), (1.0, 1.0, 1.0), 16.0)
+    if phong >= 2:
+        b.light((-3.0, 1.0, 4.5), (0.0, 0.0, 0.02), (0.2, 0.3, 0.5), (1.0, 1.0, 1.0), 4.0)
     return b.build("small", make_camera((0, 0, 0), (0, 0, 1)))
 
 
@@ -178,6 +196,8 @@ def by_name(name: str) -> Scene:
         return small_scene(bubble=True)
     if name == "small_light":
         return small_scene(light=True)
+    if name == "small_phong":
+        return small_scene(phong=2)
     if name == "random_spheres":
         return random_spheres_scene()
     if name == "grid10k":

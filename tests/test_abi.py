@@ -28,11 +28,12 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    from raytracer_amd.api import CAMERA_DTYPE, MATERIAL_DTYPE, SPHERE_DTYPE, _Params
+    from raytracer_amd.api import CAMERA_DTYPE, LIGHT_DTYPE, MATERIAL_DTYPE, SPHERE_DTYPE, _Params
 
     assert SPHERE_DTYPE.itemsize == 16
-    assert MATERIAL_DTYPE.itemsize == 40 and MATERIAL_DTYPE.fields["emission"][1] == 24
-    assert CAMERA_DTYPE.itemsize == 48
+    assert MATERIAL_DTYPE.itemsize == 48 and MATERIAL_DTYPE.fields["emission"][1] == 24
+    assert MATERIAL_DTYPE.fields["diffuse"][1] == 36
+    assert CAMERA_DTYPE.itemsize == 48 and LIGHT_DTYPE.itemsize == 64
     assert ctypes.sizeof(_Params) == 36
 
 

@@ -7,7 +7,8 @@ r=Renderer(0); s=scenes.random_spheres_scene(); r.set_scene(s)
 lib=api.load_library()
 out=(C.c_ulonglong*8)()
 lib.rt_debug_read(out)
-p=RenderParams(1200,675,samples_per_pixel=500,max_depth=50)
+W,H,SPP=int(sys.argv[1]),int(sys.argv[2]),int(sys.argv[3])
+p=RenderParams(W,H,samples_per_pixel=SPP,max_depth=50)
 rgba,acc,rays=r.render_host(p)
 lib.rt_debug_read(out)
 o=list(out)
