@@ -108,6 +108,28 @@ kats["viewport"] = [
 # points along +z exactly (y = 0) -> a = 0.5 -> (0.75, 0.85, 1.0)
 kats["sky"] = dict(direction_y=0.0, rgb=[0.75, 0.85, 1.0])
 
+# ---- Light::getDirectLighting through a depth-1 render (reference inc/RTObjects.h:247-257,300-320,
+# src/Camera.cpp:161-178).  Camera at (0,1,0) looking straight down at a Lambertian ground sphere
+# (centre (0,-100,0), r 100, diffuse (0.8,0.8,0)): the centre pixel's ray hits P = (0,0,0), n = (0,1,0).
+# With maxRayDepth 1 the radiance is emitted (0) + LIndirect (attenuation * black) + LDirect.
+#   light A at (0,2,0), ambient 0.1, diffuse 0.5, pow 8: toLight = toView = n, so cos = 1, the mirrored
+#     light direction is n again -> specular 1:  0.1*0.8 + 0.5*0.8 + 1 = 1.48 (r,g);  blue: 0 + 0 + 1 = 1
+#   blocker: a small sphere at (0,1.5,0) r 0.2 sits between P and the light -> shadowed: ambient only
+#   light B at (3,0,0) lies in the tangent plane: cos = 0 -> no Lambert term; mirrored direction
+#     (-1,0,0) is orthogonal to toView -> no specular: ambient only even when unshadowed
+kats["direct_light"] = dict(
+    camera=dict(center=[0, 1, 0], direction=[0, -1, 0]),
+    ground=dict(c=[0, -100, 0], r=100.0, diffuse=[0.8, 0.8, 0.0]),
+    cases=[
+        dict(name="overhead light, unshadowed", light=dict(position=[0, 2, 0], ambient=[0.1] * 3, diffuse=[0.5] * 3,
+             view_pow=8.0), blocker=None, rgb=[1.48, 1.48, 1.0]),
+        dict(name="overhead light, blocked", light=dict(position=[0, 2, 0], ambient=[0.1] * 3, diffuse=[0.5] * 3,
+             view_pow=8.0), blocker=dict(c=[0, 1.5, 0], r=0.2), rgb=[0.08, 0.08, 0.0]),
+        dict(name="light in the tangent plane", light=dict(position=[3, 0, 0], ambient=[0.25] * 3, diffuse=[0.5] * 3,
+             view_pow=2.0), blocker=None, rgb=[0.2, 0.2, 0.0]),
+    ],
+)
+
 # ---- random words: regression vector of the generator both sides share ------------------------
 # (pcg4d as written in oracle/rt_oracle.c; values produced by a straight Python transcription)
 def pcg4d(x, y, z, w):

@@ -458,3 +458,15 @@ def test_direct_lighting_matches_oracle(renderer, oracle64, n_lights, depth):
     flagged = RenderParams(W, H, samples_per_pixel=8, max_depth=depth, seed=21, flags=FLAG_DIRECT_LIGHT)
     b, _, _ = renderer.render_host(flagged)
     assert np.array_equal(a, base) and np.array_equal(a, b)
+
+
+def test_gpu_direct_light_kats(renderer):
+    from raytracer_amd.api import FLAG_DIRECT_LIGHT
+    from tests.test_oracle import direct_light_scene
+
+    for case in KATS["direct_light"]["cases"]:
+        renderer.set_scene(direct_light_scene(case))
+        N = 401
+        _, acc, rays = renderer.render_host(RenderParams(N, N, 1, 1, seed=1, flags=FLAG_DIRECT_LIGHT), want_accum=True)
+        assert np.allclose(acc[N // 2, N // 2, :3], case["rgb"], atol=0.02), case["name"]
+        assert rays == 2 * N * N

@@ -149,3 +149,24 @@ def test_single_precision_oracle_agrees(oracle64, oracle32):
     a, acc_a, _ = oracle64.render(scene, 64, 36, 64, 10, seed=7)
     b, acc_b, _ = oracle32.render(scene, 64, 36, 64, 10, seed=7)
     assert np.allclose(acc_a.mean(axis=(0, 1)), acc_b.mean(axis=(0, 1)), rtol=5e-3)
+
+
+def direct_light_scene(case):
+    k = KATS["direct_light"]
+    b = scenes._Builder()
+    b.sphere(k["ground"]["c"], k["ground"]["r"], b.lambertian(k["ground"]["diffuse"]))
+    if case["blocker"]:
+        b.sphere(case["blocker"]["c"], case["blocker"]["r"], b.lambertian((0.5, 0.5, 0.5)))
+    lt = case["light"]
+    b.light(lt["position"], lt["ambient"], lt["diffuse"], (1, 1, 1), lt["view_pow"])
+    return b.build("kat", scenes.make_camera(k["camera"]["center"], k["camera"]["direction"]))
+
+
+@pytest.mark.parametrize("case", KATS["direct_light"]["cases"], ids=[c["name"] for c in KATS["direct_light"]["cases"]])
+def test_direct_light_kats(oracle64, case):
+    """Depth-1 render: the centre pixel of a fine frame is LDirect at P = (0,0,0), n = (0,1,0)."""
+    scene = direct_light_scene(case)
+    N = 401  # the jitter moves the hit point by < 1/401 of the viewport
+    _, acc, rays = oracle64.render(scene, N, N, 1, 1, seed=1, y0=N // 2, y1=N // 2 + 1, direct_light=True)
+    assert np.allclose(acc[N // 2, N // 2], case["rgb"], atol=0.02)
+    assert rays == 2 * N  # one primary + one shadow query per pixel of the row (every ray hits the ground)
