@@ -53,6 +53,33 @@ typedef struct rt_sphere {
     float cx, cy, cz, r;
 } rt_sphere;
 
+/* Primitive kinds: the Primitives subclasses the render path can meet
+ * (reference inc/RTObjects.h:85 SphereObject, :162 PlaneObject, :323 PolygonObject, :543 CubeObject). */
+enum {
+    RT_PRIM_SPHERE = 0,
+    RT_PRIM_PLANE = 1,
+    RT_PRIM_CUBE = 2,
+    RT_PRIM_POLYGON = 3
+};
+
+/* One primitive of a general scene, 64 bytes.  The array index is the object id: insertion
+ * order, which is also the tie-break order of hitClosest.
+ *   sphere  : p = centre xyz, radius
+ *   plane   : p = point xyz, normal xyz             (PlaneObject::position_, normal_)
+ *   cube    : p = centre xyz, half size xyz         (axis-aligned; CubeObject::halfSize_)
+ *   polygon : p = unit normal xyz, centroid xyz     (PolygonObject::normal_, position_) and the
+ *             vertices first_vertex .. first_vertex + n_vertices - 1 of the vertex array
+ *   selected: Primitives::selected_ — the object shows the red selection halo (:96-105) */
+typedef struct rt_prim {
+    uint32_t type;
+    uint32_t mat;
+    uint32_t first_vertex;
+    uint32_t n_vertices;
+    float p[8];
+    uint32_t selected;
+    uint32_t _pad[3];
+} rt_prim;
+
 /* One material, flattened.
  *   albedo   : RTLambertian::diffuse_ / RTMetal::specular_ / RTDielectric::specular_local_
  *              (the colour scatter() returns as attenuation, inc/RTMaterial.h:78,113,147)
@@ -143,6 +170,13 @@ const char *rt_last_error(const rt_ctx *ctx);
 int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_spheres,
                     const uint32_t *h_mat_id, int n_mats, const rt_material *h_mats);
 
+/* Same for a scene that also holds planes, axis-aligned cubes, planar polygons or selected
+ * objects (Primitives::hit / hitExpanded of each kind, reference inc/RTObjects.h:174-194,
+ * 370-386, 455-512, 560-568, 586-644; halo pass src/RayTracer.cpp:84-97).
+ * h_vertices holds n_vertices xyz triples (polygon corners, world space); may be NULL when 0. */
+int rt_upload_scene_ex(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertices,
+                       const float *h_vertices, int n_mats, const rt_material *h_mats);
+
 /* Replaces SceneManager's light list as read by Camera::computeDirectLighting
  * (reference src/Camera.cpp:161-178, inc/RayTracer.h:26,30).  n_lights may be 0. */
 int rt_upload_lights(rt_ctx *ctx, int n_lights, const rt_light *h_lights);
@@ -171,8 +205,10 @@ int rt_render_host(rt_ctx *ctx, const rt_params *p, uint8_t *h_rgba, float *h_ac
 
 /* First-hit flags */
 enum {
-    RT_FH_REFINE = 1u << 0 /* re-test numerically ambiguous rays in fp64 so that the
-                              returned id equals a double-precision evaluation */
+    RT_FH_REFINE = 1u << 0,  /* re-test numerically ambiguous rays in fp64 so that the
+                                returned id equals a double-precision evaluation */
+    RT_FH_EXPANDED = 1u << 1 /* hitExpandedState = true: add the selection-halo pass
+                                (src/RayTracer.cpp:84-97) */
 };
 
 /* Replaces SceneManager::hitClosest(ray, Interval(tmin, +inf), rec, false)
@@ -191,6 +227,16 @@ int rt_first_hit_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *
 int rt_first_hit(rt_ctx *ctx, int n_rays, const float *d_org, const float *d_dir,
                  float tmin, uint32_t flags, int32_t *d_id, float *d_t, float *d_normal,
                  uint8_t *d_front, void *stream);
+
+/* The same two calls with HitRecord::hitExpanded as one more output (0/1, may be NULL): set when
+ * the ray met the grown shell of a selected object before anything else.  For a general scene
+ * `id` is the index into the rt_prim array. */
+int rt_first_hit_ex_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir,
+                         float tmin, uint32_t flags, int32_t *h_id, float *h_t,
+                         float *h_normal, uint8_t *h_front, uint8_t *h_expanded);
+int rt_first_hit_ex(rt_ctx *ctx, int n_rays, const float *d_org, const float *d_dir,
+                    float tmin, uint32_t flags, int32_t *d_id, float *d_t, float *d_normal,
+                    uint8_t *d_front, uint8_t *d_expanded, void *stream);
 
 /* Replaces RTMaterial::scatter (reference inc/RTMaterial.h:67-80,105-115,142-170,
  * 205-207) for a batch of hits, with the three uniform variates the bounce would

@@ -19,6 +19,8 @@ MATERIAL_DTYPE = np.dtype(
 )
 LIGHT_DTYPE = np.dtype([("position", "<f4", 3), ("ambient", "<f4", 3), ("diffuse", "<f4", 3), ("specular", "<f4", 3),
                         ("view_pow", "<f4"), ("_pad", "<f4", 3)])
+PRIM_DTYPE = np.dtype([("type", "<u4"), ("mat", "<u4"), ("first_vertex", "<u4"), ("n_vertices", "<u4"), ("p", "<f4", 8),
+                       ("selected", "<u4"), ("_pad", "<u4", 3)])
 CAMERA_DTYPE = np.dtype([("center", "<f4", 3), ("upper_left", "<f4", 3), ("right", "<f4", 3), ("down", "<f4", 3)])
 
 
@@ -41,9 +43,10 @@ class Oracle:
         L = self.lib
         vp, i32, u32 = C.c_void_p, C.c_int, C.c_uint32
         L.orc_rng4.argtypes = [u32, u32, u32, u32, C.POINTER(u32)]
-        L.orc_render.argtypes = [i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, u32, i32, i32, i32, i32, vp, vp]
+        L.orc_render.argtypes = [i32, vp, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, u32, i32, i32, i32,
+                                 i32, vp, vp]
         L.orc_render.restype = C.c_uint64
-        L.orc_first_hit.argtypes = [i32, vp, i32, vp, vp, C.c_double, vp, vp, vp, vp, vp]
+        L.orc_first_hit.argtypes = [i32, vp, i32, vp, vp, i32, i32, vp, vp, C.c_double, vp, vp, vp, vp, vp, vp]
         L.orc_scatter.argtypes = [i32] + [vp] * 11
         L.orc_sample_radiance.argtypes = [i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, u32, i32, vp]
         L.orc_primary_rays.argtypes = [vp, i32, i32, u32, i32, i32, vp, vp]
@@ -62,14 +65,29 @@ class Oracle:
         cam = np.ascontiguousarray(scene.camera, dtype=CAMERA_DTYPE)
         return sph, mid, mats, cam
 
+    @staticmethod
+    def _general_args(scene, general=None):
+        """(prims, verts, n_prims) of the general primitive list, or (None, None, 0) for the sphere arrays."""
+        prims = getattr(scene, "prims", None)
+        if general is None:
+            general = prims is not None and len(prims) > 0 and getattr(scene, "needs_general", False)
+        if not general or prims is None:
+            return None, None, 0
+        prims = np.ascontiguousarray(prims, dtype=PRIM_DTYPE)
+        verts = np.ascontiguousarray(scene.verts, dtype=np.float32).reshape(-1)
+        if len(verts) == 0:
+            verts = np.zeros(3, np.float32)
+        return prims, verts, len(prims)
+
     def rng4(self, pixel, sample, call, seed):
         out = (C.c_uint32 * 4)()
         self.lib.orc_rng4(pixel, sample, call, seed, out)
         return np.array(list(out), dtype=np.uint32)
 
     def render(self, scene, W, H, spp, max_depth, seed=0, samples_per_scatter=1, sample_offset=0,
-               iterative=False, y0=0, y1=None, want_accum=True, direct_light=False):
-        """direct_light=True renders with enableLDirect and the scene's lights."""
+               iterative=False, y0=0, y1=None, want_accum=True, direct_light=False, general=None):
+        """direct_light=True renders with enableLDirect and the scene's lights.
+        general: use the scene's general primitive list (default: when it holds non-sphere or selected items)."""
         sph, mid, mats, cam = self._scene_args(scene)
         lights = getattr(scene, "lights", None)
         if not direct_light or lights is None or len(lights) == 0:
@@ -79,13 +97,17 @@ class Oracle:
             n_l = len(lights)
         rgba = np.zeros((H, W, 4), np.uint8)
         accum = np.zeros((H, W, 3), np.float64) if want_accum else None
-        rays = self.lib.orc_render(len(sph), _p(sph), _p(mid), len(mats), _p(mats), n_l, _p(lights), _p(cam), W, H, spp,
+        prims, verts, n_p = self._general_args(scene, general)
+        rays = self.lib.orc_render(len(sph), _p(sph), _p(mid), len(mats), _p(mats), n_l, _p(lights), n_p, _p(prims),
+                                   _p(verts), _p(cam), W, H, spp,
                                    samples_per_scatter, max_depth, seed, sample_offset, 1 if iterative else 0,
                                    y0, H if y1 is None else y1, _p(rgba), _p(accum))
         return rgba, accum, int(rays)
 
-    def first_hit(self, scene, org, dir, tmin=0.001, want_margin=False):
+    def first_hit(self, scene, org, dir, tmin=0.001, want_margin=False, general=None, expanded_state=False,
+                  want_expanded=False):
         sph = np.ascontiguousarray(scene.spheres, dtype=SPHERE_DTYPE)
+        prims, verts, n_p = self._general_args(scene, general)
         org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
         dir = np.ascontiguousarray(dir, np.float32).reshape(-1, 3)
         n = len(org)
@@ -94,8 +116,11 @@ class Oracle:
         nrm = np.zeros((n, 3), np.float64)
         front = np.zeros(n, np.uint8)
         margin = np.zeros(n, np.float64) if want_margin else None
-        self.lib.orc_first_hit(len(sph), _p(sph), n, _p(org), _p(dir), float(tmin), _p(ids), _p(t), _p(nrm),
-                               _p(front), _p(margin))
+        hexp = np.zeros(n, np.uint8)
+        self.lib.orc_first_hit(len(sph), _p(sph), n_p, _p(prims), _p(verts), 1 if expanded_state else 0, n, _p(org),
+                               _p(dir), float(tmin), _p(ids), _p(t), _p(nrm), _p(front), _p(hexp), _p(margin))
+        if want_expanded:
+            return ids, t, nrm, front, margin, hexp
         return ids, t, nrm, front, margin
 
     def scatter(self, mats, mat, in_dir, point, normal, front, u):

@@ -57,6 +57,20 @@ typedef struct {
 } orc_light;
 typedef struct { float center[3], upper_left[3], right[3], down[3]; } orc_camera;
 
+/* One primitive of a general scene (same layout as rt_prim in include/rt_amd.h):
+ *   sphere : p = centre xyz, radius                    (SphereObject, inc/RTObjects.h:85-160)
+ *   plane  : p = point xyz, normal xyz                 (PlaneObject, :162-218)
+ *   cube   : p = centre xyz, half size xyz             (CubeObject, :543-645)
+ *   polygon: p = normal xyz, centroid xyz; vertices [first_vertex, first_vertex + n_vertices)
+ *            of the vertex array, xyz each             (PolygonObject, :323-540) */
+enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_CUBE = 2, PRIM_POLYGON = 3 };
+typedef struct {
+    uint32_t type, mat, first_vertex, n_vertices;
+    float p[8];
+    uint32_t selected;
+    uint32_t _pad[3];
+} orc_prim;
+
 enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_EMISSIVE = 3 };
 
 typedef struct { real x, y, z; } vec3;
@@ -70,14 +84,22 @@ typedef struct {
     int n_lights;             /* 0 unless direct lighting is enabled */
     const orc_light *lights;
     vec3 cam_center;          /* Camera::center_, read by computeDirectLighting */
+    int n_prims;              /* > 0: general scene (the sphere arrays above are then unused) */
+    const orc_prim *prims;
+    const float *verts;
 } scene_t;
+
+#define OBJ_NONE (-1) /* no hit */
+#define OBJ_NULL (-2) /* a hit whose HitRecord::object is nullptr (cube, polygon: inc/RTObjects.h:507,642) */
 
 /* HitRecord, reference inc/RTGeometry.h:49-62 (material/object pointers become indices) */
 typedef struct {
     vec3 point, normal;
-    int object;
+    int object;      /* HitRecord::object: primitive index, OBJ_NONE or OBJ_NULL */
+    int prim;        /* primitive index of the hit (material lookup) */
     int front;
     real time;
+    int hit_expanded; /* HitRecord::hitExpanded */
 } hitrec;
 
 static real r_sqrt(real x) { return (real)sqrt((double)x); }
@@ -186,26 +208,202 @@ static int hit_sphere(vec3 O, vec3 D, real tmin, real tmax, vec3 C, real radius,
     vec3 nn = vnormalized(outward);
     rec->normal = rec->front ? nn : vmuls(nn, -1);
     rec->object = id;
+    rec->prim = id;
     return 1;
 }
 
-/* SceneManager::hitClosest main loop, reference src/RayTracer.cpp:68-82
- * (the selection-halo pass :84-97 is inert without selected objects). */
-static int hit_closest(const scene_t *s, vec3 O, vec3 D, real tmin, real tmax, hitrec *rec) {
-    hitrec tmp;
-    memset(&tmp, 0, sizeof tmp);
-    tmp.object = -1;
-    real closest = tmax;
-    int any = 0;
-    for (int i = 0; i < s->n; i++) {
-        const orc_sphere *sp = &s->sph[i];
-        if (hit_sphere(O, D, tmin, closest, v3((real)sp->cx, (real)sp->cy, (real)sp->cz), (real)sp->r, i, &tmp)) {
-            any = 1;
-            closest = tmp.time;
+/* HitRecord::setFaceNormal, reference inc/RTGeometry.h:58-61 */
+static void set_face_normal(hitrec *rec, vec3 D, vec3 outward) {
+    rec->front = vdot(D, outward) < 0;
+    vec3 nn = vnormalized(outward);
+    rec->normal = rec->front ? nn : vmuls(nn, -1);
+}
+
+/* PlaneObject::hit, reference inc/RTObjects.h:174-190.  The "outward" normal is turned along the ray
+ * before setFaceNormal, so a plane always reports frontFace == false. */
+static int hit_plane(vec3 O, vec3 D, real tmin, real tmax, const orc_prim *pr, int id, hitrec *rec) {
+    vec3 pos = vf(pr->p), n = vf(pr->p + 3);
+    real time = vdot(n, vsub(pos, O)) * ((real)1.0 / vdot(n, D));
+    if (!surrounds(tmin, tmax, time)) return 0;
+    rec->object = id;
+    rec->prim = id;
+    rec->time = time;
+    rec->point = vadd(O, vmuls(D, time));
+    vec3 outward = n;
+    if (vdot(n, D) < 0) outward = vmuls(n, -1);
+    set_face_normal(rec, D, outward);
+    return 1;
+}
+
+/* CubeObject::hitBox, reference inc/RTObjects.h:586-644 (axis-aligned slab test; the normal is picked
+ * by which face the point lies within 1e-6 of, else by the dominant local axis; object stays null). */
+static int hit_box(vec3 O, vec3 D, real tmin_i, real tmax_i, vec3 center, vec3 half, int id, hitrec *rec) {
+    const real EPS = (real)1e-6;
+    real tmin = (real)-INFINITY, tmax = (real)INFINITY;
+    real orig[3] = {O.x, O.y, O.z}, dir[3] = {D.x, D.y, D.z};
+    real minB[3] = {center.x - half.x, center.y - half.y, center.z - half.z};
+    real maxB[3] = {center.x + half.x, center.y + half.y, center.z + half.z};
+    for (int i = 0; i < 3; ++i) {
+        if ((real)fabs((double)dir[i]) < (real)1e-12) {
+            if (orig[i] < minB[i] || orig[i] > maxB[i]) return 0;
+        } else {
+            real invD = (real)1.0 / dir[i];
+            real t0 = (minB[i] - orig[i]) * invD, t1 = (maxB[i] - orig[i]) * invD;
+            if (t0 > t1) { real tt = t0; t0 = t1; t1 = tt; }
+            tmin = tmin > t0 ? tmin : t0;
+            tmax = tmax < t1 ? tmax : t1;
+            if (tmax < tmin) return 0;
         }
     }
-    *rec = tmp;
+    real t = tmin;
+    if (!surrounds(tmin_i, tmax_i, t)) {
+        t = tmax;
+        if (!surrounds(tmin_i, tmax_i, t)) return 0;
+    }
+    rec->time = t;
+    rec->point = vadd(O, vmuls(D, t));
+    vec3 P = rec->point, out = v3(0, 0, 0);
+    if ((real)fabs((double)(P.x - minB[0])) < EPS) out = v3(-1, 0, 0);
+    else if ((real)fabs((double)(P.x - maxB[0])) < EPS) out = v3(1, 0, 0);
+    else if ((real)fabs((double)(P.y - minB[1])) < EPS) out = v3(0, -1, 0);
+    else if ((real)fabs((double)(P.y - maxB[1])) < EPS) out = v3(0, 1, 0);
+    else if ((real)fabs((double)(P.z - minB[2])) < EPS) out = v3(0, 0, -1);
+    else if ((real)fabs((double)(P.z - maxB[2])) < EPS) out = v3(0, 0, 1);
+    else {
+        vec3 l = vsub(P, center);
+        real ax = (real)fabs((double)l.x), ay = (real)fabs((double)l.y), az = (real)fabs((double)l.z);
+        if (ax > ay && ax > az) out = v3(l.x > 0 ? 1 : -1, 0, 0);
+        else if (ay > az) out = v3(0, l.y > 0 ? 1 : -1, 0);
+        else out = v3(0, 0, l.z > 0 ? 1 : -1);
+    }
+    set_face_normal(rec, D, out);
+    rec->object = OBJ_NULL;
+    rec->prim = id;
+    return 1;
+}
+
+/* PolygonObject::projectTo2D, reference inc/RTObjects.h:444-453: drop the dominant axis of the normal */
+static void project2d(vec3 n, vec3 p, real *u, real *v) {
+    real ax = (real)fabs((double)n.x), ay = (real)fabs((double)n.y), az = (real)fabs((double)n.z);
+    if (ax > ay && ax > az) { *u = p.y; *v = p.z; }
+    else if (ay > az) { *u = p.x; *v = p.z; }
+    else { *u = p.x; *v = p.y; }
+}
+
+/* PolygonObject::hitDetail + pointInPolygon2D, reference inc/RTObjects.h:455-512: plane through the
+ * centroid, even-odd crossing test in the projected plane.  `scale` = 1, or EXPAND_COEF for the halo
+ * (vertices pushed away from the centroid, :375-381). */
+static int hit_polygon(vec3 O, vec3 D, real tmin, real tmax, const orc_prim *pr, const float *verts, real scale,
+                       int id, hitrec *rec) {
+    int nv = (int)pr->n_vertices;
+    if (nv < 3) return 0;
+    vec3 n = vf(pr->p), centroid = vf(pr->p + 3);
+    real denom = vdot(n, D);
+    if ((real)fabs((double)denom) < (real)1e-12) return 0;
+    real t = vdot(n, vsub(centroid, O)) / denom;
+    if (!surrounds(tmin, tmax, t)) return 0;
+    vec3 P = vadd(O, vmuls(D, t));
+    real px, py;
+    project2d(n, P, &px, &py);
+    int inside = 0;
+    const float *vv = verts + 3 * pr->first_vertex;
+    for (int i = 0, j = nv - 1; i < nv; j = i++) {
+        vec3 vi = vf(vv + 3 * i), vj = vf(vv + 3 * j);
+        if (scale != (real)1) {
+            vec3 si = vmuls(vsub(vi, centroid), scale), sj = vmuls(vsub(vj, centroid), scale);
+            vi = v3(centroid.x + si.x, centroid.y + si.y, centroid.z + si.z);
+            vj = v3(centroid.x + sj.x, centroid.y + sj.y, centroid.z + sj.z);
+        }
+        real xi, yi, xj, yj;
+        project2d(n, vi, &xi, &yi);
+        project2d(n, vj, &xj, &yj);
+        int intersect = ((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi + (real)1e-20) + xi);
+        if (intersect) inside = !inside;
+    }
+    if (!inside) return 0;
+    rec->time = t;
+    rec->point = P;
+    vec3 outward = n;
+    if (vdot(n, D) > 0) outward = vmuls(n, -1);
+    set_face_normal(rec, D, outward);
+    rec->object = OBJ_NULL;
+    rec->prim = id;
+    return 1;
+}
+
+static const real EXPAND_COEF = (real)1.05; /* Primitives::EXPAND_COEF, reference inc/RTObjects.h:26 */
+
+/* Primitives::hit for a general primitive (virtual dispatch of src/RayTracer.cpp:78) */
+static int prim_hit(const scene_t *s, int i, vec3 O, vec3 D, real tmin, real tmax, hitrec *rec) {
+    const orc_prim *pr = &s->prims[i];
+    switch (pr->type) {
+    case PRIM_SPHERE: return hit_sphere(O, D, tmin, tmax, vf(pr->p), (real)pr->p[3], i, rec);
+    case PRIM_PLANE: return hit_plane(O, D, tmin, tmax, pr, i, rec);
+    case PRIM_CUBE: return hit_box(O, D, tmin, tmax, vf(pr->p), vf(pr->p + 3), i, rec);
+    default: return hit_polygon(O, D, tmin, tmax, pr, s->verts, (real)1, i, rec);
+    }
+}
+
+/* Primitives::hitExpanded (selection halo): sphere inc/RTObjects.h:96-105, plane :192-194 (a plane answers
+ * with its plain hit whether selected or not), polygon :370-386, cube :560-568. */
+static int prim_hit_expanded(const scene_t *s, int i, vec3 O, vec3 D, real tmin, real tmax, hitrec *rec) {
+    const orc_prim *pr = &s->prims[i];
+    if (pr->type == PRIM_PLANE) return hit_plane(O, D, tmin, tmax, pr, i, rec);
+    if (!pr->selected) return 0;
+    if (prim_hit(s, i, O, D, tmin, tmax, rec)) return 1;
+    int res;
+    if (pr->type == PRIM_SPHERE)
+        res = hit_sphere(O, D, tmin, tmax, vf(pr->p), (real)pr->p[3] * EXPAND_COEF, i, rec);
+    else if (pr->type == PRIM_CUBE)
+        res = hit_box(O, D, tmin, tmax, vf(pr->p), vmuls(vf(pr->p + 3), EXPAND_COEF), i, rec);
+    else
+        res = hit_polygon(O, D, tmin, tmax, pr, s->verts, EXPAND_COEF, i, rec);
+    if (res) rec->hit_expanded = 1;
+    return res;
+}
+
+/* SceneManager::hitClosest, reference src/RayTracer.cpp:68-100.  `expanded_state` is the
+ * hitExpandedState argument (true for primary rays only, src/Camera.cpp:141): it adds the
+ * selection-halo pass :84-97, whose record persists across objects exactly as in the reference
+ * (a plain hit found through hitExpanded does not clear an earlier hitExpanded flag). */
+static int hit_closest_ex(const scene_t *s, vec3 O, vec3 D, real tmin, real tmax, int expanded_state, hitrec *rec) {
+    hitrec tmp, exp;
+    memset(&tmp, 0, sizeof tmp);
+    tmp.object = OBJ_NONE;
+    tmp.prim = -1;
+    exp = tmp;
+    real closest = tmax, closest_exp = tmax;
+    int any = 0;
+    if (s->n_prims > 0) {
+        for (int i = 0; i < s->n_prims; i++) {
+            if (prim_hit(s, i, O, D, tmin, closest, &tmp)) {
+                any = 1;
+                closest = tmp.time;
+            }
+        }
+        if (expanded_state) {
+            for (int i = 0; i < s->n_prims; i++) {
+                if (prim_hit_expanded(s, i, O, D, tmin, closest_exp, &exp)) {
+                    any = 1;
+                    closest_exp = exp.time;
+                }
+            }
+        }
+    } else {
+        for (int i = 0; i < s->n; i++) {
+            const orc_sphere *sp = &s->sph[i];
+            if (hit_sphere(O, D, tmin, closest, v3((real)sp->cx, (real)sp->cy, (real)sp->cz), (real)sp->r, i, &tmp)) {
+                any = 1;
+                closest = tmp.time;
+            }
+        }
+    }
+    *rec = closest_exp < closest ? exp : tmp;
     return any;
+}
+
+static int hit_closest(const scene_t *s, vec3 O, vec3 D, real tmin, real tmax, hitrec *rec) {
+    return hit_closest_ex(s, O, D, tmin, tmax, 0, rec);
 }
 
 /* RTDielectric::reflectance, reference inc/RTMaterial.h:193-197 */
@@ -288,8 +486,6 @@ static vec3 light_direct(const orc_light *lt, vec3 to_view, const hitrec *rec, c
     return vadd(ambient, vmuls(vadd(diffuse, specular), shadow));
 }
 
-static int hit_closest(const scene_t *s, vec3 O, vec3 D, real tmin, real tmax, hitrec *rec);
-
 /* Camera::computeDirectLighting, reference src/Camera.cpp:161-178: one closest-hit query per light
  * along the (unnormalised, unbounded) ray towards it; a hit on the shaded object itself does not count. */
 static vec3 direct_lighting(const scene_t *s, const hitrec *rec, const orc_material *m, uint64_t *rays) {
@@ -310,7 +506,12 @@ typedef struct {
     const scene_t *s;
     int samples_per_scatter;
     uint64_t rays;
+    int max_depth; /* renderProperties.maxRayDepth: the halo pass runs when depth == max_depth */
 } trace_ctx;
+
+static const orc_material *material_of(const scene_t *s, const hitrec *rec) {
+    return &s->mats[s->n_prims > 0 ? s->prims[rec->prim].mat : s->mat_id[rec->prim]];
+}
 
 /* sky colour on a miss, reference src/Camera.cpp:155-156 (direction used as is) */
 static vec3 sky(vec3 d) {
@@ -324,9 +525,10 @@ static vec3 ray_color(trace_ctx *tc, rng_t *g, vec3 O, vec3 D, int depth) {
     if (depth == 0) return v3(0, 0, 0);
     hitrec rec;
     tc->rays++;
-    if (hit_closest(tc->s, O, D, TMIN, (real)INFINITY, &rec)) {
-        const orc_material *m = &tc->s->mats[tc->s->mat_id[rec.object]];
+    if (hit_closest_ex(tc->s, O, D, TMIN, (real)INFINITY, depth == tc->max_depth, &rec)) {
+        const orc_material *m = material_of(tc->s, &rec);
         vec3 emitted = vf(m->emission);
+        if (rec.hit_expanded) emitted = v3(1, 0, 0); /* selection colour, src/Camera.cpp:144-147 */
         vec3 lind = v3(0, 0, 0);
         for (int i = 0; i < tc->samples_per_scatter; i++) {
             real u[4];
@@ -349,12 +551,12 @@ static vec3 ray_color_iter(trace_ctx *tc, rng_t *g, vec3 O, vec3 D, int max_dept
     for (int depth = max_depth; depth > 0; depth--) {
         hitrec rec;
         tc->rays++;
-        if (!hit_closest(tc->s, O, D, TMIN, (real)INFINITY, &rec)) {
+        if (!hit_closest_ex(tc->s, O, D, TMIN, (real)INFINITY, depth == max_depth, &rec)) {
             L = vadd(L, vmul(T, sky(D)));
             break;
         }
-        const orc_material *m = &tc->s->mats[tc->s->mat_id[rec.object]];
-        L = vadd(L, vmul(T, vf(m->emission)));
+        const orc_material *m = material_of(tc->s, &rec);
+        L = vadd(L, vmul(T, rec.hit_expanded ? v3(1, 0, 0) : vf(m->emission)));
         if (tc->s->n_lights) L = vadd(L, vmul(T, direct_lighting(tc->s, &rec, m, &tc->rays)));
         real u[4];
         rng_next(g, u);
@@ -396,23 +598,26 @@ ORC_API void orc_convert_color(const double rgb[3], uint8_t out[4]) {
 /* Camera::renderParallel + renderPixelColor, reference src/Camera.cpp:69-88,105-122.
  * gm::setThreadSeed(pixelId) (:84) becomes "the stream is keyed on pixelId".
  *   iterative != 0 selects ray_color_iter (requires samples_per_scatter == 1).
+ *   n_prims > 0 renders the general primitive list `prims` (+ polygon vertices `verts`) instead of the
+ *   sphere arrays; selected primitives get the halo on primary rays.
  *   n_lights > 0 enables Camera::computeDirectLighting (enableLDirect) with those lights.
  *   rows [y0, y1) are rendered; rgba/accum are full W*H buffers (accum: W*H*3 doubles,
  *   per-pixel sample SUM; may be NULL).  sample_offset shifts the sample index.
  * Returns the number of hitClosest calls. */
 ORC_API uint64_t orc_render(int n, const orc_sphere *sph, const uint32_t *mat_id, int n_mats,
                             const orc_material *mats, int n_lights, const orc_light *lights,
+                            int n_prims, const orc_prim *prims, const float *verts,
                             const orc_camera *cam, int W, int H, int spp,
                             int samples_per_scatter, int max_depth, uint32_t seed, int sample_offset,
                             int iterative, int y0, int y1, uint8_t *rgba, double *accum) {
-    scene_t s = {n, sph, mat_id, n_mats, mats, n_lights, lights, vf(cam->center)};
+    scene_t s = {n, sph, mat_id, n_mats, mats, n_lights, lights, vf(cam->center), n_prims, prims, verts};
     uint64_t total = 0;
     if (y0 < 0) y0 = 0;
     if (y1 > H) y1 = H;
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : total)
     for (int pid = y0 * W; pid < y1 * W; pid++) {
         int px = pid % W, py = pid / W;
-        trace_ctx tc = {&s, samples_per_scatter, 0};
+        trace_ctx tc = {&s, samples_per_scatter, 0, max_depth};
         vec3 sum = v3(0, 0, 0);
         for (int smp = 0; smp < spp; smp++) {
             rng_t g = {(uint32_t)pid, (uint32_t)(smp + sample_offset), 0, seed};
@@ -447,16 +652,18 @@ ORC_API uint64_t orc_render(int n, const orc_sphere *sph, const uint32_t *mat_id
  * min over spheres of |disc|/(hb^2 + |a*c|), and over hit spheres of the relative
  * distance of a root to tmin or to the winning t — small values mark rays whose id a
  * lower-precision evaluation may legitimately get wrong. */
-ORC_API void orc_first_hit(int n, const orc_sphere *sph, int n_rays, const float *org, const float *dir,
+ORC_API void orc_first_hit(int n, const orc_sphere *sph, int n_prims, const orc_prim *prims, const float *verts,
+                           int expanded_state, int n_rays, const float *org, const float *dir,
                            double tmin, int32_t *id, double *t, double *normal, uint8_t *front,
-                           double *margin) {
-    scene_t s = {n, sph, NULL, 0, NULL, 0, NULL, {0, 0, 0}};
+                           uint8_t *hit_expanded, double *margin) {
+    scene_t s = {n, sph, NULL, 0, NULL, 0, NULL, {0, 0, 0}, n_prims, prims, verts};
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n_rays; i++) {
         vec3 O = vf(org + 3 * i), D = vf(dir + 3 * i);
         hitrec rec;
-        int any = hit_closest(&s, O, D, (real)tmin, (real)INFINITY, &rec);
-        id[i] = any ? rec.object : -1;
+        int any = hit_closest_ex(&s, O, D, (real)tmin, (real)INFINITY, expanded_state, &rec);
+        id[i] = any ? rec.prim : -1;
+        if (hit_expanded) hit_expanded[i] = any ? (uint8_t)rec.hit_expanded : 0;
         if (t) t[i] = any ? (double)rec.time : 0.0;
         if (normal) {
             normal[3 * i + 0] = any ? (double)rec.normal.x : 0.0;
@@ -464,7 +671,7 @@ ORC_API void orc_first_hit(int n, const orc_sphere *sph, int n_rays, const float
             normal[3 * i + 2] = any ? (double)rec.normal.z : 0.0;
         }
         if (front) front[i] = any ? (uint8_t)rec.front : 0;
-        if (margin) {
+        if (margin && n_prims == 0) {
             double best = any ? (double)rec.time : INFINITY;
             double m = INFINITY;
             for (int k = 0; k < n; k++) {
@@ -504,6 +711,7 @@ ORC_API void orc_scatter(int n, const orc_material *mats, const uint32_t *mat, c
                          uint8_t *scattered) {
     for (int i = 0; i < n; i++) {
         hitrec rec;
+        memset(&rec, 0, sizeof rec);
         rec.point = v3((real)point[3 * i], (real)point[3 * i + 1], (real)point[3 * i + 2]);
         rec.normal = v3((real)normal[3 * i], (real)normal[3 * i + 1], (real)normal[3 * i + 2]);
         rec.front = front[i];
@@ -525,8 +733,8 @@ ORC_API void orc_sample_radiance(int n, const orc_sphere *sph, const uint32_t *m
                                  const orc_material *mats, const orc_camera *cam, int W, int H, int pid,
                                  int smp, int samples_per_scatter, int max_depth, uint32_t seed,
                                  int iterative, double out[3]) {
-    scene_t s = {n, sph, mat_id, n_mats, mats, 0, NULL, vf(cam->center)};
-    trace_ctx tc = {&s, samples_per_scatter, 0};
+    scene_t s = {n, sph, mat_id, n_mats, mats, 0, NULL, vf(cam->center), 0, NULL, NULL};
+    trace_ctx tc = {&s, samples_per_scatter, 0, max_depth};
     rng_t g = {(uint32_t)pid, (uint32_t)smp, 0, seed};
     real u[4];
     rng_next(&g, u);

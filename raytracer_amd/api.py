@@ -18,6 +18,7 @@ STRIP_ROWS = 8
 FLAG_ACCUMULATE = 1
 FLAG_DIRECT_LIGHT = 2
 FH_REFINE = 1
+FH_EXPANDED = 2
 
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
 
@@ -28,9 +29,12 @@ MATERIAL_DTYPE = np.dtype(
 )
 LIGHT_DTYPE = np.dtype([("position", "<f4", 3), ("ambient", "<f4", 3), ("diffuse", "<f4", 3), ("specular", "<f4", 3),
                         ("view_pow", "<f4"), ("_pad", "<f4", 3)])
+PRIM_DTYPE = np.dtype([("type", "<u4"), ("mat", "<u4"), ("first_vertex", "<u4"), ("n_vertices", "<u4"), ("p", "<f4", 8),
+                       ("selected", "<u4"), ("_pad", "<u4", 3)])
+PRIM_SPHERE, PRIM_PLANE, PRIM_CUBE, PRIM_POLYGON = 0, 1, 2, 3
 CAMERA_DTYPE = np.dtype([("center", "<f4", 3), ("upper_left", "<f4", 3), ("right", "<f4", 3), ("down", "<f4", 3)])
 assert SPHERE_DTYPE.itemsize == 16 and MATERIAL_DTYPE.itemsize == 48 and CAMERA_DTYPE.itemsize == 48
-assert LIGHT_DTYPE.itemsize == 64
+assert LIGHT_DTYPE.itemsize == 64 and PRIM_DTYPE.itemsize == 64
 
 
 class RtError(RuntimeError):
@@ -74,8 +78,8 @@ class RenderParams:
 
 EXPORTS = [
     "rt_version", "rt_rng4", "rt_output_rows", "rt_create", "rt_destroy", "rt_last_error",
-    "rt_upload_scene", "rt_upload_lights", "rt_set_camera", "rt_render", "rt_render_host", "rt_first_hit",
-    "rt_first_hit_host", "rt_scatter_host",
+    "rt_upload_scene", "rt_upload_scene_ex", "rt_upload_lights", "rt_set_camera", "rt_render", "rt_render_host",
+    "rt_first_hit", "rt_first_hit_host", "rt_first_hit_ex", "rt_first_hit_ex_host", "rt_scatter_host",
 ]
 
 _lib = None
@@ -106,6 +110,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_upload_scene.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     lib.rt_upload_scene.restype = C.c_int
+    lib.rt_upload_scene_ex.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
+    lib.rt_upload_scene_ex.restype = C.c_int
     lib.rt_upload_lights.argtypes = [vp, C.c_int, vp]
     lib.rt_upload_lights.restype = C.c_int
     lib.rt_set_camera.argtypes = [vp, vp]
@@ -118,6 +124,10 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rt_first_hit.restype = C.c_int
     lib.rt_first_hit_host.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp]
     lib.rt_first_hit_host.restype = C.c_int
+    lib.rt_first_hit_ex.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp, vp]
+    lib.rt_first_hit_ex.restype = C.c_int
+    lib.rt_first_hit_ex_host.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp]
+    lib.rt_first_hit_ex_host.restype = C.c_int
     lib.rt_scatter_host.argtypes = [vp, C.c_int] + [vp] * 10
     lib.rt_scatter_host.restype = C.c_int
     if path is None:
@@ -189,6 +199,19 @@ class Renderer:
         )
         self.n_spheres = len(spheres)
 
+    def upload_scene_ex(self, prims: np.ndarray, verts: np.ndarray | None, mats: np.ndarray):
+        """General primitive list (spheres, planes, cubes, polygons, selection flags)."""
+        prims = np.ascontiguousarray(prims, dtype=PRIM_DTYPE)
+        mats = np.ascontiguousarray(mats, dtype=MATERIAL_DTYPE)
+        nv = 0 if verts is None else len(verts)
+        v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3) if nv else None
+        self._check(
+            self.lib.rt_upload_scene_ex(self.h, len(prims), _ptr(prims) if len(prims) else None, nv,
+                                        _ptr(v) if nv else None, len(mats), _ptr(mats)),
+            "rt_upload_scene_ex",
+        )
+        self.n_spheres = int(np.count_nonzero(prims["type"] == PRIM_SPHERE))
+
     def upload_lights(self, lights: np.ndarray | None):
         n = 0 if lights is None else len(lights)
         arr = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE) if n else None
@@ -200,7 +223,10 @@ class Renderer:
 
     def set_scene(self, scene):
         """scene: a scenes.Scene"""
-        self.upload_scene(scene.spheres, scene.mat_id, scene.mats)
+        if getattr(scene, "needs_general", False):
+            self.upload_scene_ex(scene.prims, scene.verts, scene.mats)
+        else:
+            self.upload_scene(scene.spheres, scene.mat_id, scene.mats)
         self.upload_lights(getattr(scene, "lights", None))
         self.set_camera(scene.camera)
 
@@ -239,7 +265,10 @@ class Renderer:
         )
 
     # -- first hit / scatter --------------------------------------------------
-    def first_hit(self, org: np.ndarray, dir: np.ndarray, tmin: float = 0.001, refine: bool = False):
+    def first_hit(self, org: np.ndarray, dir: np.ndarray, tmin: float = 0.001, refine: bool = False,
+                  expanded_state: bool = False, want_expanded: bool = False):
+        """SceneManager::hitClosest for a batch of rays.  Returns (ids, t, normal, front) and, with
+        want_expanded, HitRecord::hitExpanded as a fifth array."""
         org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
         dir = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
         n = len(org)
@@ -247,12 +276,21 @@ class Renderer:
         t = np.zeros(n, dtype=np.float32)
         nrm = np.zeros((n, 3), dtype=np.float32)
         front = np.zeros(n, dtype=np.uint8)
+        flags = (FH_REFINE if refine else 0) | (FH_EXPANDED if expanded_state else 0)
+        if not (expanded_state or want_expanded):
+            self._check(
+                self.lib.rt_first_hit_host(self.h, n, _ptr(org), _ptr(dir), float(tmin), flags,
+                                           _ptr(ids), _ptr(t), _ptr(nrm), _ptr(front)),
+                "rt_first_hit_host",
+            )
+            return ids, t, nrm, front
+        exp = np.zeros(n, dtype=np.uint8)
         self._check(
-            self.lib.rt_first_hit_host(self.h, n, _ptr(org), _ptr(dir), float(tmin), FH_REFINE if refine else 0,
-                                       _ptr(ids), _ptr(t), _ptr(nrm), _ptr(front)),
-            "rt_first_hit_host",
+            self.lib.rt_first_hit_ex_host(self.h, n, _ptr(org), _ptr(dir), float(tmin), flags,
+                                          _ptr(ids), _ptr(t), _ptr(nrm), _ptr(front), _ptr(exp)),
+            "rt_first_hit_ex_host",
         )
-        return ids, t, nrm, front
+        return (ids, t, nrm, front, exp) if want_expanded else (ids, t, nrm, front)
 
     def scatter(self, mat, in_dir, point, normal, front, u):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 3)

@@ -24,6 +24,7 @@
 
 #include "../../include/rt_amd.h"
 #include "rt_device.h"
+#include "rt_prims.h"
 
 using namespace rt;
 
@@ -63,6 +64,7 @@ struct DeviceScene {
     const uint32_t *mat_id;
     const DMat *mats;
     const DLight *lights;
+    FullScene full; // general primitive list (used by the FULL kernel variants only)
 };
 
 // Where the scan loop takes the sphere words from.
@@ -166,7 +168,8 @@ struct Path {
 struct LightState {
     int light_i;   // -1: the lane traces its path ray; k >= 0: the shadow ray towards light k
     V3 hp, hn;     // the shaded hit (HitRecord::point / normal)
-    int hobj, hmat; // its object and material index
+    int hobj, hmat; // its HitRecord::object code and material index
+    int hself;      // packed index of the sphere the hit lies on exactly, else -1
     V3 nxt_o, nxt_d, att; // the bounce to resume with
     int nxt_self;
     bool nxt_valid; // false: the path ends after the shadow queries
@@ -209,7 +212,7 @@ __device__ __forceinline__ Tile decode_item(const KParams &p, unsigned item) {
 // items from one global counter until it runs dry, so the grid stays busy however
 // uneven the image is.  Inside an item the wave runs the path loop described at the
 // top of this file.
-template <int SRC, bool LIGHTS>
+template <int SRC, bool FULL>
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
     ls.light_i = -1;
     ls.hp = ls.hn = ls.nxt_o = ls.nxt_d = ls.att = mk(0, 0, 0);
     ls.hobj = ls.hmat = 0;
+    ls.hself = -1;
     ls.nxt_self = -1;
     ls.nxt_valid = false;
     const V3 cam_center = mk(p.cam[0], p.cam[1], p.cam[2]);
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
             if (!have_item) break;
         }
 
-        const bool in_shadow = LIGHTS && ls.light_i >= 0;
+        const bool in_shadow = FULL && ls.light_i >= 0;
         const bool active = pt.pix >= 0 && (pt.depth > 0 || in_shadow);
         // a path with no depth left (max_depth == 0) contributes black and ends at once
         bool finished = pt.pix >= 0 && pt.depth <= 0 && !in_shadow;
@@ -319,33 +323,66 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
         float4 at = make_float4(0, 0, 0, 0), ef = make_float4(0, 0, 0, 0);
         float ior = 1.f;
         int hit_mat = 0;
-        const bool shadow_ray = LIGHTS && ls.light_i >= 0;
+        int next_self = -1; // packed index of the sphere a diffuse / metal bounce starts on
+        const bool shadow_ray = FULL && ls.light_i >= 0;
         if (active) {
             my_rays++;
             if (pt.self_id >= 0) self_hit(pt.o, pt.dh, tmin, sc.sph[pt.self_id], pt.self_id, best_t, best_id);
+            // the winner of the scan; FULL: merged with the other primitive kinds and the selection halo
+            bool any_hit = best_id >= 0;
+            int hit_obj = best_id; // HitRecord::object code
+            int hit_self = best_id;
+            bool halo = false;
+            Closest c;
+            if (FULL) {
+                c.t = any_hit ? best_t * pt.inv_len : __builtin_inff();
+                c.prim = any_hit ? sc.full.sph_gid[best_id] : -1;
+                c.scale = 1.0f;
+                c.box_face = 0;
+                c.expanded = false;
+                for (int k = 0; k < sc.full.n_others; ++k) other_hit(sc.full, sc.full.others[k], pt.o, pt.d, TMIN, c);
+                // the halo pass runs for primary rays only (hitExpandedState, src/Camera.cpp:141)
+                if (!shadow_ray && sc.full.n_halo > 0 && pt.depth == p.max_depth) {
+                    Closest e = halo_pass(sc.full, pt.o, pt.d, TMIN);
+                    if (e.t < c.t) c = e;
+                }
+                any_hit = c.prim >= 0;
+            }
             if (!shadow_ray) {
                 pt.depth--;
-                if (best_id < 0) {
+                if (!any_hit) {
                     pt.L = pt.L + pt.T * sky(pt.d);
                     finished = true;
                 } else {
-                    h = finish_hit(pt.o, pt.d, best_t * pt.inv_len, sc.sph[best_id]);
-                    hit_mat = (int)sc.mat_id[best_id];
+                    if (FULL) {
+                        h = finish_any(sc.full, pt.o, pt.d, c, hit_obj);
+                        const DPrim &pr = sc.full.prims[c.prim];
+                        hit_mat = (int)pr.mat;
+                        hit_self = (pr.type == PRIM_SPHERE && c.scale == 1.0f) ? pr.sph_local : -1;
+                        halo = c.expanded;
+                    } else {
+                        h = finish_hit(pt.o, pt.d, best_t * pt.inv_len, sc.sph[best_id]);
+                        hit_mat = (int)sc.mat_id[best_id];
+                    }
                     const DMat &m = sc.mats[hit_mat];
                     at = m.albedo_type;
                     ef = m.emission_fuzz;
                     ior = m.ior_diffuse.x;
-                    pt.L = pt.L + pt.T * mk(ef.x, ef.y, ef.z);
+                    // a halo hit glows in the selection colour instead (src/Camera.cpp:144-147)
+                    pt.L = pt.L + pt.T * (halo ? mk(1.0f, 0.0f, 0.0f) : mk(ef.x, ef.y, ef.z));
                     // an emissive surface ends the path (RTEmissive::scatter, inc/RTMaterial.h:205-207); so does
                     // running out of depth: the next getRayColor would return black (src/Camera.cpp:138)
                     if (__float_as_uint(at.w) == 3u || pt.depth == 0) finished = true;
                     else bounce = true;
-                    if (LIGHTS && p.n_lights > 0) {
+                    // diffuse and metal bounces start exactly on the sphere; the dielectric nudges its origin
+                    next_self = __float_as_uint(at.w) <= 1u ? hit_self : -1;
+                    if (FULL && p.n_lights > 0) {
                         // Camera::computeDirectLighting (src/Camera.cpp:161-178): the hit is kept, the shadow
                         // queries run in the following iterations, then the path resumes or ends
                         ls.hp = h.p;
                         ls.hn = h.n;
-                        ls.hobj = best_id;
+                        ls.hobj = hit_obj;
+                        ls.hself = hit_self;
                         ls.hmat = hit_mat;
                         ls.nxt_valid = bounce;
                         ls.light_i = 0;
@@ -354,8 +391,13 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
                 }
             } else {
                 // the closest hit along the ray towards the light; a hit on the shaded object itself does
-                // not count (src/Camera.cpp:169-172)
-                const bool hitted = best_id >= 0 && best_id != ls.hobj;
+                // not count, and cubes / polygons all carry the same null object (src/Camera.cpp:169-172)
+                int obj = OBJ_NONE;
+                if (any_hit) {
+                    const uint32_t ty = sc.full.prims[c.prim].type;
+                    obj = (ty == PRIM_CUBE || ty == PRIM_POLYGON) ? OBJ_NULL : c.prim;
+                }
+                const bool hitted = any_hit && obj != ls.hobj;
                 float4 idf = sc.mats[ls.hmat].ior_diffuse;
                 pt.L = pt.L + pt.T * light_direct(sc.lights[ls.light_i], cam_center, ls.hp, ls.hn,
                                                   mk(idf.y, idf.z, idf.w), hitted);
@@ -431,15 +473,14 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
             V3 nd;
             if (fresh) {
                 gen_ray(p, px, py, u01(w0), u01(w1), pt.o, nd);
-                if (LIGHTS) ls.light_i = -1;
+                if (FULL) ls.light_i = -1;
                 set_dir(pt, nd);
             } else {
                 V3 att, no;
                 scatter(__float_as_uint(at.w), mk(at.x, at.y, at.z), ef.w, ior, pt.d, h, u01(w0), u01(w1), u01(w2), att,
                         no, nd);
-                // diffuse and metal bounces start exactly on the sphere; the dielectric nudges its origin
-                const int nself = __float_as_uint(at.w) <= 1u ? best_id : -1;
-                if (LIGHTS && p.n_lights > 0) {
+                const int nself = next_self;
+                if (FULL && p.n_lights > 0) {
                     ls.nxt_o = no;
                     ls.nxt_d = nd;
                     ls.att = att;
@@ -452,13 +493,13 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
                 }
             }
         }
-        if (LIGHTS && ls.light_i >= 0 && pt.pix >= 0) {
+        if (FULL && ls.light_i >= 0 && pt.pix >= 0) {
             // (next) shadow ray: from the hit point towards the light, direction unnormalised as in
             // the reference (src/Camera.cpp:166)
             float4 lp = sc.lights[ls.light_i].pos_pow;
             pt.o = ls.hp;
             set_dir(pt, mk(lp.x, lp.y, lp.z) - ls.hp);
-            pt.self_id = ls.hobj;
+            pt.self_id = ls.hself;
         }
 
         // ---- tile done: tone-map and store (convertRTColor, src/Camera.cpp:19-34) ----
@@ -536,14 +577,191 @@ __device__ __noinline__ void finish64(double ox, double oy, double oz, double dx
     if (n_out) { n_out[0] = (float)nx; n_out[1] = (float)ny; n_out[2] = (float)nz; }
     if (front) *front = f ? 1 : 0;
 }
+
+// Double-precision closest hit over a general primitive list: the same decisions as
+// SceneManager::hitClosest with Primitives::hit / hitExpanded of every kind
+// (src/RayTracer.cpp:68-100; inc/RTObjects.h:129-159 sphere, :174-190 plane, :469-512 polygon,
+// :586-644 cube), evaluated operation by operation as a host double evaluation would.
+struct D3 {
+    double x, y, z;
+};
+__device__ __forceinline__ D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+__device__ __forceinline__ D3 dsub(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 dat(D3 o, D3 d, double t) { return d3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t); }
+
+struct Rec64 {
+    double t;
+    int prim;
+    D3 n;
+    bool front, expanded;
+};
+
+// HitRecord::setFaceNormal, inc/RTGeometry.h:58-61
+__device__ __forceinline__ void face64(Rec64 &rec, D3 d, D3 outward) {
+    rec.front = ddot(d, outward) < 0.0;
+    double len = sqrt(ddot(outward, outward));
+    D3 nn = d3(outward.x / len, outward.y / len, outward.z / len);
+    rec.n = rec.front ? nn : d3(-nn.x, -nn.y, -nn.z);
+}
+
+__device__ __noinline__ bool prim_hit64(const FullScene &fs, int idx, D3 o, D3 d, double tmin, double tmax, double scale,
+                                        Rec64 &rec) {
+    const DPrim &pr = fs.prims[idx];
+    if (pr.type == PRIM_SPHERE) {
+        double r = (double)pr.p[3] * scale, t;
+        if (!hit64(o.x, o.y, o.z, d.x, d.y, d.z, tmin, tmax, pr.p[0], pr.p[1], pr.p[2], r, t)) return false;
+        D3 pt = dat(o, d, t);
+        D3 w = d3((pt.x - pr.p[0]) / r, (pt.y - pr.p[1]) / r, (pt.z - pr.p[2]) / r);
+        rec.t = t;
+        face64(rec, d, w);
+    } else if (pr.type == PRIM_PLANE) {
+        D3 pos = d3(pr.p[0], pr.p[1], pr.p[2]), n = d3(pr.p[3], pr.p[4], pr.p[5]);
+        double t = ddot(n, dsub(pos, o)) * (1.0 / ddot(n, d));
+        if (!(tmin < t && t < tmax)) return false;
+        rec.t = t;
+        face64(rec, d, ddot(n, d) < 0.0 ? d3(-n.x, -n.y, -n.z) : n);
+    } else if (pr.type == PRIM_CUBE) {
+        double lo_t = -__builtin_inf(), hi_t = __builtin_inf();
+        const double orig[3] = {o.x, o.y, o.z}, dir[3] = {d.x, d.y, d.z};
+        double lo[3], hi[3];
+        for (int i = 0; i < 3; ++i) {
+            double hs = (double)pr.p[3 + i] * scale;
+            lo[i] = (double)pr.p[i] - hs;
+            hi[i] = (double)pr.p[i] + hs;
+        }
+        for (int i = 0; i < 3; ++i) {
+            if (fabs(dir[i]) < 1e-12) {
+                if (orig[i] < lo[i] || orig[i] > hi[i]) return false;
+            } else {
+                double inv = 1.0 / dir[i];
+                double t0 = (lo[i] - orig[i]) * inv, t1 = (hi[i] - orig[i]) * inv;
+                if (t0 > t1) { double tt = t0; t0 = t1; t1 = tt; }
+                lo_t = lo_t > t0 ? lo_t : t0;
+                hi_t = hi_t < t1 ? hi_t : t1;
+                if (hi_t < lo_t) return false;
+            }
+        }
+        double t = lo_t;
+        if (!(tmin < t && t < tmax)) {
+            t = hi_t;
+            if (!(tmin < t && t < tmax)) return false;
+        }
+        D3 pt = dat(o, d, t), out = d3(0, 0, 0);
+        const double EPS = 1e-6;
+        if (fabs(pt.x - lo[0]) < EPS) out = d3(-1, 0, 0);
+        else if (fabs(pt.x - hi[0]) < EPS) out = d3(1, 0, 0);
+        else if (fabs(pt.y - lo[1]) < EPS) out = d3(0, -1, 0);
+        else if (fabs(pt.y - hi[1]) < EPS) out = d3(0, 1, 0);
+        else if (fabs(pt.z - lo[2]) < EPS) out = d3(0, 0, -1);
+        else if (fabs(pt.z - hi[2]) < EPS) out = d3(0, 0, 1);
+        else {
+            D3 l = d3(pt.x - pr.p[0], pt.y - pr.p[1], pt.z - pr.p[2]);
+            double ax = fabs(l.x), ay = fabs(l.y), az = fabs(l.z);
+            if (ax > ay && ax > az) out = d3(l.x > 0 ? 1 : -1, 0, 0);
+            else if (ay > az) out = d3(0, l.y > 0 ? 1 : -1, 0);
+            else out = d3(0, 0, l.z > 0 ? 1 : -1);
+        }
+        rec.t = t;
+        face64(rec, d, out);
+    } else {
+        const int nv = (int)pr.n_vertices;
+        if (nv < 3) return false;
+        D3 n = d3(pr.p[0], pr.p[1], pr.p[2]), cen = d3(pr.p[3], pr.p[4], pr.p[5]);
+        double denom = ddot(n, d);
+        if (fabs(denom) < 1e-12) return false;
+        double t = ddot(n, dsub(cen, o)) / denom;
+        if (!(tmin < t && t < tmax)) return false;
+        D3 pt = dat(o, d, t);
+        // PolygonObject::projectTo2D: drop the dominant axis of the normal
+        double ax = fabs(n.x), ay = fabs(n.y), az = fabs(n.z);
+        const int drop = (ax > ay && ax > az) ? 0 : (ay > az ? 1 : 2);
+        auto uv = [&](D3 q, double &u, double &v) {
+            if (drop == 0) { u = q.y; v = q.z; }
+            else if (drop == 1) { u = q.x; v = q.z; }
+            else { u = q.x; v = q.y; }
+        };
+        auto vertex = [&](int k) {
+            const float *vv = fs.verts + 3 * ((size_t)pr.first_vertex + (size_t)k);
+            D3 v = d3(vv[0], vv[1], vv[2]);
+            if (scale != 1.0) {
+                D3 sd = d3((v.x - cen.x) * scale, (v.y - cen.y) * scale, (v.z - cen.z) * scale);
+                v = d3(cen.x + sd.x, cen.y + sd.y, cen.z + sd.z);
+            }
+            return v;
+        };
+        double px, py;
+        uv(pt, px, py);
+        bool inside = false;
+        for (int i = 0, j = nv - 1; i < nv; j = i++) {
+            double xi, yi, xj, yj;
+            uv(vertex(i), xi, yi);
+            uv(vertex(j), xj, yj);
+            bool cross = ((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi + 1e-20) + xi);
+            if (cross) inside = !inside;
+        }
+        if (!inside) return false;
+        rec.t = t;
+        face64(rec, d, ddot(n, d) > 0.0 ? d3(-n.x, -n.y, -n.z) : n);
+    }
+    rec.prim = idx;
+    return true;
+}
+
+__device__ __noinline__ Rec64 closest64_general(const FullScene &fs, int n_prims, D3 o, D3 d, double tmin,
+                                                bool expanded_state) {
+    Rec64 rec, ex;
+    rec.t = 0.0;
+    rec.prim = -1;
+    rec.n = d3(0, 0, 0);
+    rec.front = rec.expanded = false;
+    ex = rec;
+    double closest = __builtin_inf(), closest_ex = __builtin_inf();
+    for (int i = 0; i < n_prims; ++i)
+        if (prim_hit64(fs, i, o, d, tmin, closest, 1.0, rec)) closest = rec.t;
+    if (expanded_state) {
+        for (int k = 0; k < fs.n_halo; ++k) {
+            const int i = fs.halo[k];
+            const uint32_t ty = fs.prims[i].type;
+            bool ok = prim_hit64(fs, i, o, d, tmin, closest_ex, 1.0, ex);
+            if (!ok && ty != PRIM_PLANE) {
+                ok = prim_hit64(fs, i, o, d, tmin, closest_ex, (double)1.05, ex);
+                if (ok) ex.expanded = true; // never cleared by a later plain hit, as in the reference
+            }
+            if (ok) closest_ex = ex.t;
+        }
+    }
+    return closest_ex < closest ? ex : rec;
+}
 #pragma clang fp contract(fast)
 
 template <bool REFINE>
 __global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const float *__restrict__ org,
                                                                const float *__restrict__ dir, float tmin,
-                                                               DeviceScene sc, int n_spheres, int32_t *__restrict__ id,
+                                                               DeviceScene sc, int n_spheres, int n_prims, int general,
+                                                               int expanded_state, int32_t *__restrict__ id,
                                                                float *__restrict__ t, float *__restrict__ normal,
-                                                               uint8_t *__restrict__ front) {
+                                                               uint8_t *__restrict__ front,
+                                                               uint8_t *__restrict__ expanded) {
+    // general: the scene holds other primitives than spheres, or the halo pass is wanted; ids are then
+    // indices into the primitive list
+    if (REFINE && general) {
+        const int i = blockIdx.x * WG_THREADS + threadIdx.x;
+        if (i >= n_rays) return;
+        Rec64 r = closest64_general(sc.full, n_prims, d3(org[3 * i], org[3 * i + 1], org[3 * i + 2]),
+                                    d3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), (double)tmin, expanded_state != 0);
+        id[i] = r.prim;
+        const bool hit = r.prim >= 0;
+        if (t) t[i] = hit ? (float)r.t : 0.f;
+        if (normal) {
+            normal[3 * i] = hit ? (float)r.n.x : 0.f;
+            normal[3 * i + 1] = hit ? (float)r.n.y : 0.f;
+            normal[3 * i + 2] = hit ? (float)r.n.z : 0.f;
+        }
+        if (front) front[i] = hit && r.front ? 1 : 0;
+        if (expanded) expanded[i] = hit && r.expanded ? 1 : 0;
+        return;
+    }
     __shared__ float4 lds_sph[4 * STREAM_QUADS];
     const int i = blockIdx.x * WG_THREADS + threadIdx.x;
     const bool live = i < n_rays;
@@ -567,6 +785,32 @@ __global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const
         if (live) scan_lds(lds_sph, cnt, 4 * base, rk, o, dh, tmin * len, -1, best_t, best_id);
     }
     best_t *= inv_len;
+    if (live && expanded) expanded[i] = 0;
+    if (!REFINE && general) {
+        if (!live) return;
+        Closest c;
+        c.t = best_id >= 0 ? best_t : __builtin_inff();
+        c.prim = best_id >= 0 ? sc.full.sph_gid[best_id] : -1;
+        c.scale = 1.0f;
+        c.box_face = 0;
+        c.expanded = false;
+        for (int k = 0; k < sc.full.n_others; ++k) other_hit(sc.full, sc.full.others[k], o, d, tmin, c);
+        if (expanded_state && sc.full.n_halo > 0) {
+            Closest e = halo_pass(sc.full, o, d, tmin);
+            if (e.t < c.t) c = e;
+        }
+        id[i] = c.prim;
+        Hit h;
+        h.p = h.n = mk(0, 0, 0);
+        h.front = false;
+        int object = OBJ_NONE;
+        if (c.prim >= 0) h = finish_any(sc.full, o, d, c, object);
+        if (t) t[i] = c.prim >= 0 ? c.t : 0.f;
+        if (normal) { normal[3 * i] = h.n.x; normal[3 * i + 1] = h.n.y; normal[3 * i + 2] = h.n.z; }
+        if (front) front[i] = h.front ? 1 : 0;
+        if (expanded) expanded[i] = c.prim >= 0 && c.expanded ? 1 : 0;
+        return;
+    }
     if (!REFINE) {
         if (!live) return;
         id[i] = best_id;
@@ -678,6 +922,11 @@ struct rt_ctx {
     DMat *d_mats = nullptr;
     DLight *d_lights = nullptr;
     int n_lights = 0;
+    // the general primitive list (every scene has one; sphere-only scenes only use it with lights)
+    DPrim *d_prims = nullptr;
+    float *d_verts = nullptr;
+    int32_t *d_others = nullptr, *d_halo = nullptr, *d_sph_gid = nullptr;
+    int n_prims = 0, n_others = 0, n_halo = 0;
     int n_spheres = 0;
     int n_mats = 0;
     bool have_scene = false;
@@ -704,6 +953,15 @@ void free_scene(rt_ctx *ctx) {
     if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
     if (ctx->d_mat_id) (void)hipFree(ctx->d_mat_id);
     if (ctx->d_mats) (void)hipFree(ctx->d_mats);
+    if (ctx->d_prims) (void)hipFree(ctx->d_prims);
+    if (ctx->d_verts) (void)hipFree(ctx->d_verts);
+    if (ctx->d_others) (void)hipFree(ctx->d_others);
+    if (ctx->d_halo) (void)hipFree(ctx->d_halo);
+    if (ctx->d_sph_gid) (void)hipFree(ctx->d_sph_gid);
+    ctx->d_prims = nullptr;
+    ctx->d_verts = nullptr;
+    ctx->d_others = ctx->d_halo = ctx->d_sph_gid = nullptr;
+    ctx->n_prims = ctx->n_others = ctx->n_halo = 0;
     ctx->d_sph = ctx->d_pairs = nullptr;
     ctx->d_mat_id = nullptr;
     ctx->d_mats = nullptr;
@@ -736,7 +994,7 @@ int local_strips(const rt_params *p) {
 
 } // namespace
 
-RT_API int rt_version(void) { return 101; }
+RT_API int rt_version(void) { return 102; }
 
 RT_API void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint32_t out[4]) {
     rng4(pixel, sample, call, seed, out[0], out[1], out[2], out[3]);
@@ -799,71 +1057,163 @@ RT_API void rt_destroy(rt_ctx *ctx) {
 
 RT_API const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+namespace {
+
+DeviceScene device_scene(const rt_ctx *ctx) {
+    DeviceScene sc;
+    sc.sph = ctx->d_sph;
+    sc.pairs = ctx->d_pairs;
+    sc.mat_id = ctx->d_mat_id;
+    sc.mats = ctx->d_mats;
+    sc.lights = ctx->d_lights;
+    sc.full.prims = ctx->d_prims;
+    sc.full.verts = ctx->d_verts;
+    sc.full.others = ctx->d_others;
+    sc.full.halo = ctx->d_halo;
+    sc.full.sph_gid = ctx->d_sph_gid;
+    sc.full.n_others = ctx->n_others;
+    sc.full.n_halo = ctx->n_halo;
+    return sc;
+}
+
+template <typename T>
+int to_device(rt_ctx *ctx, T **dst, const std::vector<T> &src) {
+    // keep at least one element allocated so kernels always get valid pointers
+    size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc((void **)dst, bytes));
+    if (!src.empty()) HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+// Builds every device array of a scene from the general primitive list.
+int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertices, const float *h_vertices,
+                 int n_mats, const rt_material *h_mats) {
+    if (n_prims < 0 || n_mats < 0 || n_vertices < 0) return fail(ctx, RT_ERR_INVALID, "negative count");
+    if (n_prims > 0 && (!h_prims || !h_mats || n_mats == 0)) return fail(ctx, RT_ERR_INVALID, "null scene array");
+    if (n_vertices > 0 && !h_vertices) return fail(ctx, RT_ERR_INVALID, "null vertex array");
+    for (int i = 0; i < n_prims; ++i) {
+        const rt_prim &pr = h_prims[i];
+        if (pr.type > RT_PRIM_POLYGON) return fail(ctx, RT_ERR_UNSUPPORTED, "unknown primitive type");
+        if (pr.mat >= (uint32_t)n_mats) return fail(ctx, RT_ERR_INVALID, "mat_id out of range");
+        if (pr.type == RT_PRIM_POLYGON &&
+            ((unsigned long long)pr.first_vertex + pr.n_vertices > (unsigned long long)n_vertices))
+            return fail(ctx, RT_ERR_INVALID, "polygon vertex range outside the vertex array");
+    }
+    for (int i = 0; i < n_mats; ++i)
+        if (h_mats[i].type > RT_MAT_EMISSIVE) return fail(ctx, RT_ERR_UNSUPPORTED, "unknown material type");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    free_scene(ctx);
+
+    std::vector<DPrim> prims((size_t)n_prims);
+    std::vector<float4> sph;
+    std::vector<uint32_t> mid;
+    std::vector<int32_t> others, halo, gid;
+    bool any_selected = false;
+    for (int i = 0; i < n_prims; ++i) any_selected = any_selected || h_prims[i].selected != 0;
+    for (int i = 0; i < n_prims; ++i) {
+        const rt_prim &h = h_prims[i];
+        DPrim &d = prims[i];
+        memset(&d, 0, sizeof d);
+        d.type = h.type;
+        d.mat = h.mat;
+        d.first_vertex = h.first_vertex;
+        d.n_vertices = h.n_vertices;
+        memcpy(d.p, h.p, sizeof d.p);
+        d.selected = h.selected ? 1u : 0u;
+        d.sph_local = -1;
+        if (h.type == RT_PRIM_SPHERE) {
+            d.sph_local = (int32_t)sph.size();
+            sph.push_back(make_float4(h.p[0], h.p[1], h.p[2], h.p[3]));
+            mid.push_back(h.mat);
+            gid.push_back(i);
+        } else {
+            others.push_back(i);
+        }
+        // the halo pass changes a result only when something is selected; a plane answers it with
+        // its plain hit whether selected or not (inc/RTObjects.h:192-194)
+        if (any_selected && (h.selected || h.type == RT_PRIM_PLANE)) halo.push_back(i);
+    }
+    const int n_spheres = (int)sph.size();
+    // pair-interleaved scan words: padded to a multiple of eight spheres with spheres that cannot
+    // be hit (r^2 = -1 makes the discriminant negative for every ray), plus four spare quads so
+    // that the scan's read-ahead never leaves the array
+    const int n_quads = ((n_spheres + 7) / 8) * 2;
+    const size_t n_slots = (size_t)(n_quads + 4) * 4;
+    std::vector<float4> pairs(n_slots, make_float4(0, 0, 0, 0)); // n_slots spheres -> n_slots/2 pairs -> n_slots words
+    for (size_t i = 0; i < n_slots; ++i) {
+        float x = 0, y = 0, z = 0, r2 = -1.0f;
+        if ((int)i < n_spheres) {
+            const float4 &sp = sph[i];
+            x = sp.x; y = sp.y; z = sp.z; r2 = sp.w * sp.w;
+        }
+        float4 &A = pairs[(i / 2) * 2], &B = pairs[(i / 2) * 2 + 1];
+        if (i % 2 == 0) { A.x = x; A.z = y; B.x = z; B.z = r2; }
+        else { A.y = x; A.w = y; B.y = z; B.w = r2; }
+    }
+    std::vector<DMat> mats((size_t)n_mats);
+    for (int i = 0; i < n_mats; ++i) {
+        DMat m;
+        const rt_material &h = h_mats[i];
+        float tbits;
+        uint32_t ty = h.type;
+        memcpy(&tbits, &ty, 4);
+        m.albedo_type = make_float4(h.albedo[0], h.albedo[1], h.albedo[2], tbits);
+        m.emission_fuzz = make_float4(h.emission[0], h.emission[1], h.emission[2], h.fuzz);
+        m.ior_diffuse = make_float4(h.ior, h.diffuse[0], h.diffuse[1], h.diffuse[2]);
+        mats[i] = m;
+    }
+    if (mats.empty()) {
+        DMat m;
+        memset(&m, 0, sizeof m);
+        mats.push_back(m);
+    }
+    std::vector<float> verts(h_vertices, h_vertices + 3 * (size_t)n_vertices);
+    int rc;
+    if ((rc = to_device(ctx, &ctx->d_sph, sph)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, &ctx->d_pairs, pairs)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, &ctx->d_mat_id, mid)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, &ctx->d_mats, mats)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, &ctx->d_prims, prims)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, &ctx->d_verts, verts)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, &ctx->d_others, others)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, &ctx->d_halo, halo)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, &ctx->d_sph_gid, gid)) != RT_OK) return rc;
+    ctx->n_spheres = n_spheres;
+    ctx->n_quads = n_quads;
+    ctx->n_mats = n_mats;
+    ctx->n_prims = n_prims;
+    ctx->n_others = (int)others.size();
+    ctx->n_halo = (int)halo.size();
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+} // namespace
+
 RT_API int rt_upload_scene(rt_ctx *ctx, int n_spheres, const rt_sphere *h_spheres, const uint32_t *h_mat_id,
                            int n_mats, const rt_material *h_mats) {
     if (!ctx) return RT_ERR_INVALID;
     if (n_spheres < 0 || n_mats < 0) return fail(ctx, RT_ERR_INVALID, "negative count");
     if (n_spheres > 0 && (!h_spheres || !h_mat_id || !h_mats || n_mats == 0))
         return fail(ctx, RT_ERR_INVALID, "null scene array");
-    for (int i = 0; i < n_spheres; ++i)
-        if (h_mat_id[i] >= (uint32_t)n_mats) return fail(ctx, RT_ERR_INVALID, "mat_id out of range");
-    for (int i = 0; i < n_mats; ++i)
-        if (h_mats[i].type > RT_MAT_EMISSIVE) return fail(ctx, RT_ERR_UNSUPPORTED, "unknown material type");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    free_scene(ctx);
-    // keep at least one element allocated so kernels always get valid pointers
-    size_t ns = (size_t)(n_spheres > 0 ? n_spheres : 1), nm = (size_t)(n_mats > 0 ? n_mats : 1);
-    std::vector<float4> sph(ns, make_float4(0, 0, 0, 0));
-    std::vector<uint32_t> mid(ns, 0);
-    std::vector<DMat> mats(nm);
-    // pair-interleaved scan words: quads padded with spheres that cannot be hit
-    // (r^2 = -1 makes the discriminant negative for every ray), plus one spare quad so
-    // that a one-quad read-ahead never leaves the array
-    const int n_quads = ((n_spheres + 7) / 8) * 2; // an even number of quads
-    const size_t n_slots = (size_t)(n_quads + 4) * 4;
-    std::vector<float4> pairs(n_slots, make_float4(0, 0, 0, 0)); // n_slots spheres -> n_slots/2 pairs -> n_slots words
-    for (size_t i = 0; i < n_slots; ++i) {
-        float x = 0, y = 0, z = 0, r2 = -1.0f;
-        if ((int)i < n_spheres) {
-            const rt_sphere &sp = h_spheres[i];
-            x = sp.cx; y = sp.cy; z = sp.cz; r2 = sp.r * sp.r;
-        }
-        float4 &A = pairs[(i / 2) * 2], &B = pairs[(i / 2) * 2 + 1];
-        if (i % 2 == 0) { A.x = x; A.z = y; B.x = z; B.z = r2; }
-        else { A.y = x; A.w = y; B.y = z; B.w = r2; }
-    }
+    std::vector<rt_prim> prims((size_t)n_spheres);
     for (int i = 0; i < n_spheres; ++i) {
-        const rt_sphere &sp = h_spheres[i];
-        sph[i] = make_float4(sp.cx, sp.cy, sp.cz, sp.r);
-        mid[i] = h_mat_id[i];
+        rt_prim &pr = prims[i];
+        memset(&pr, 0, sizeof pr);
+        pr.type = RT_PRIM_SPHERE;
+        pr.mat = h_mat_id[i];
+        pr.p[0] = h_spheres[i].cx;
+        pr.p[1] = h_spheres[i].cy;
+        pr.p[2] = h_spheres[i].cz;
+        pr.p[3] = h_spheres[i].r;
     }
-    for (size_t i = 0; i < nm; ++i) {
-        DMat m;
-        memset(&m, 0, sizeof m);
-        if ((int)i < n_mats) {
-            const rt_material &h = h_mats[i];
-            float tbits;
-            uint32_t ty = h.type;
-            memcpy(&tbits, &ty, 4);
-            m.albedo_type = make_float4(h.albedo[0], h.albedo[1], h.albedo[2], tbits);
-            m.emission_fuzz = make_float4(h.emission[0], h.emission[1], h.emission[2], h.fuzz);
-            m.ior_diffuse = make_float4(h.ior, h.diffuse[0], h.diffuse[1], h.diffuse[2]);
-        }
-        mats[i] = m;
-    }
-    HIP_TRY(ctx, hipMalloc(&ctx->d_sph, ns * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_pairs, n_slots * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_mat_id, ns * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_mats, nm * sizeof(DMat)));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_sph, sph.data(), ns * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_pairs, pairs.data(), n_slots * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_mat_id, mid.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_mats, mats.data(), nm * sizeof(DMat), hipMemcpyHostToDevice));
-    ctx->n_spheres = n_spheres;
-    ctx->n_quads = n_quads;
-    ctx->n_mats = n_mats;
-    ctx->have_scene = true;
-    return RT_OK;
+    return upload_prims(ctx, n_spheres, prims.data(), 0, nullptr, n_mats, h_mats);
+}
+
+RT_API int rt_upload_scene_ex(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertices,
+                              const float *h_vertices, int n_mats, const rt_material *h_mats) {
+    if (!ctx) return RT_ERR_INVALID;
+    return upload_prims(ctx, n_prims, h_prims, n_vertices, h_vertices, n_mats, h_mats);
 }
 
 RT_API int rt_upload_lights(rt_ctx *ctx, int n_lights, const rt_light *h_lights) {
@@ -945,7 +1295,7 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     memcpy(k.cam + 3, ctx->cam.upper_left, 12);
     memcpy(k.cam + 6, ctx->cam.right, 12);
     memcpy(k.cam + 9, ctx->cam.down, 12);
-    DeviceScene sc{ctx->d_sph, ctx->d_pairs, ctx->d_mat_id, ctx->d_mats, ctx->d_lights};
+    DeviceScene sc = device_scene(ctx);
     long long items = (long long)nstrips * k.tiles_per_strip;
     if (items > 0x7fffffffLL) return fail(ctx, RT_ERR_INVALID, "too many tiles for one call");
     k.n_items = (int)items;
@@ -959,7 +1309,8 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     float4 *o_acc = (float4 *)d_accum;
     unsigned long long *o_rays = (unsigned long long *)d_rays;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 256, st));
-    const bool lights = k.n_lights > 0;
+    // the general kernel serves lights, the non-sphere primitives and the selection halo
+    const bool lights = k.n_lights > 0 || ctx->n_others > 0 || ctx->n_halo > 0;
     size_t lds = ACC_BYTES;
     int src = SRC_SCALAR;
     if (!ctx->scalar_source) {
@@ -1015,25 +1366,34 @@ RT_API int rt_render_host(rt_ctx *ctx, const rt_params *p, uint8_t *h_rgba, floa
     return RT_OK;
 }
 
-RT_API int rt_first_hit(rt_ctx *ctx, int n_rays, const float *d_org, const float *d_dir, float tmin, uint32_t flags,
-                        int32_t *d_id, float *d_t, float *d_normal, uint8_t *d_front, void *stream) {
+RT_API int rt_first_hit_ex(rt_ctx *ctx, int n_rays, const float *d_org, const float *d_dir, float tmin,
+                           uint32_t flags, int32_t *d_id, float *d_t, float *d_normal, uint8_t *d_front,
+                           uint8_t *d_expanded, void *stream) {
     if (!ctx) return RT_ERR_INVALID;
     if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
     if (n_rays < 0) return fail(ctx, RT_ERR_INVALID, "negative ray count");
     if (n_rays == 0) return RT_OK;
     if (!d_org || !d_dir || !d_id) return fail(ctx, RT_ERR_INVALID, "null ray/id array");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DeviceScene sc{ctx->d_sph, ctx->d_pairs, ctx->d_mat_id, ctx->d_mats, ctx->d_lights};
+    DeviceScene sc = device_scene(ctx);
+    const int expanded_state = (flags & RT_FH_EXPANDED) ? 1 : 0;
+    const int general = (ctx->n_others > 0 || (expanded_state && ctx->n_halo > 0)) ? 1 : 0;
     dim3 grid((unsigned)((n_rays + WG_THREADS - 1) / WG_THREADS)), block(WG_THREADS);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (flags & RT_FH_REFINE)
         hipLaunchKernelGGL(first_hit_kernel<true>, grid, block, 0, st, n_rays, d_org, d_dir, tmin, sc, ctx->n_spheres,
-                           d_id, d_t, d_normal, d_front);
+                           ctx->n_prims, general, expanded_state, d_id, d_t, d_normal, d_front, d_expanded);
     else
         hipLaunchKernelGGL(first_hit_kernel<false>, grid, block, 0, st, n_rays, d_org, d_dir, tmin, sc,
-                           ctx->n_spheres, d_id, d_t, d_normal, d_front);
+                           ctx->n_spheres, ctx->n_prims, general, expanded_state, d_id, d_t, d_normal, d_front,
+                           d_expanded);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
+}
+
+RT_API int rt_first_hit(rt_ctx *ctx, int n_rays, const float *d_org, const float *d_dir, float tmin, uint32_t flags,
+                        int32_t *d_id, float *d_t, float *d_normal, uint8_t *d_front, void *stream) {
+    return rt_first_hit_ex(ctx, n_rays, d_org, d_dir, tmin, flags, d_id, d_t, d_normal, d_front, nullptr, stream);
 }
 
 namespace {
@@ -1047,8 +1407,9 @@ struct DevBuf {
 };
 } // namespace
 
-RT_API int rt_first_hit_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir, float tmin,
-                             uint32_t flags, int32_t *h_id, float *h_t, float *h_normal, uint8_t *h_front) {
+RT_API int rt_first_hit_ex_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir, float tmin,
+                                uint32_t flags, int32_t *h_id, float *h_t, float *h_normal, uint8_t *h_front,
+                                uint8_t *h_expanded) {
     if (!ctx) return RT_ERR_INVALID;
     if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
     if (n_rays < 0) return fail(ctx, RT_ERR_INVALID, "negative ray count");
@@ -1056,24 +1417,31 @@ RT_API int rt_first_hit_host(rt_ctx *ctx, int n_rays, const float *h_org, const 
     if (!h_org || !h_dir || !h_id) return fail(ctx, RT_ERR_INVALID, "null ray/id array");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     size_t n = (size_t)n_rays;
-    DevBuf org, dir, id, t, nrm, fr;
+    DevBuf org, dir, id, t, nrm, fr, ex;
     HIP_TRY(ctx, org.alloc(n * 12));
     HIP_TRY(ctx, dir.alloc(n * 12));
     HIP_TRY(ctx, id.alloc(n * 4));
     HIP_TRY(ctx, t.alloc(n * 4));
     HIP_TRY(ctx, nrm.alloc(n * 12));
     HIP_TRY(ctx, fr.alloc(n));
+    HIP_TRY(ctx, ex.alloc(n));
     HIP_TRY(ctx, hipMemcpy(org.p, h_org, n * 12, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dir.p, h_dir, n * 12, hipMemcpyHostToDevice));
-    int rc = rt_first_hit(ctx, n_rays, (const float *)org.p, (const float *)dir.p, tmin, flags, (int32_t *)id.p,
-                          (float *)t.p, (float *)nrm.p, (uint8_t *)fr.p, nullptr);
+    int rc = rt_first_hit_ex(ctx, n_rays, (const float *)org.p, (const float *)dir.p, tmin, flags, (int32_t *)id.p,
+                             (float *)t.p, (float *)nrm.p, (uint8_t *)fr.p, (uint8_t *)ex.p, nullptr);
     if (rc != RT_OK) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, hipMemcpy(h_id, id.p, n * 4, hipMemcpyDeviceToHost));
     if (h_t) HIP_TRY(ctx, hipMemcpy(h_t, t.p, n * 4, hipMemcpyDeviceToHost));
     if (h_normal) HIP_TRY(ctx, hipMemcpy(h_normal, nrm.p, n * 12, hipMemcpyDeviceToHost));
     if (h_front) HIP_TRY(ctx, hipMemcpy(h_front, fr.p, n, hipMemcpyDeviceToHost));
+    if (h_expanded) HIP_TRY(ctx, hipMemcpy(h_expanded, ex.p, n, hipMemcpyDeviceToHost));
     return RT_OK;
+}
+
+RT_API int rt_first_hit_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir, float tmin,
+                             uint32_t flags, int32_t *h_id, float *h_t, float *h_normal, uint8_t *h_front) {
+    return rt_first_hit_ex_host(ctx, n_rays, h_org, h_dir, tmin, flags, h_id, h_t, h_normal, h_front, nullptr);
 }
 
 RT_API int rt_scatter_host(rt_ctx *ctx, int n, const uint32_t *h_mat, const float *h_in_dir, const float *h_point,

@@ -14,7 +14,9 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .api import CAMERA_DTYPE, LIGHT_DTYPE, MATERIAL_DTYPE, SPHERE_DTYPE, MAT_DIELECTRIC, MAT_EMISSIVE, MAT_LAMBERTIAN, MAT_METAL
+from .api import (CAMERA_DTYPE, LIGHT_DTYPE, MATERIAL_DTYPE, PRIM_DTYPE, SPHERE_DTYPE, PRIM_CUBE, PRIM_PLANE,
+                  PRIM_POLYGON, PRIM_SPHERE)
+from .api import MAT_DIELECTRIC, MAT_EMISSIVE, MAT_LAMBERTIAN, MAT_METAL
 
 
 @dataclass
@@ -25,6 +27,13 @@ class Scene:
     mats: np.ndarray  # MATERIAL_DTYPE [m]
     camera: np.ndarray  # CAMERA_DTYPE [1]
     lights: np.ndarray = None  # LIGHT_DTYPE [l] (Phong point lights; used with direct lighting only)
+    prims: np.ndarray = None  # PRIM_DTYPE [p]: the general primitive list in insertion order
+    verts: np.ndarray = None  # float32 [v, 3]: polygon vertices
+    needs_general: bool = False  # holds planes / cubes / polygons or selected primitives
+
+    @property
+    def n_prims(self) -> int:
+        return len(self.prims) if self.prims is not None else 0
 
     @property
     def n_spheres(self) -> int:
@@ -58,6 +67,37 @@ class _Builder:
         self.mid = []
         self.mats = []
         self.lights = []
+        self.prims = []  # (type, mat, p[8], first_vertex, n_vertices, selected)
+        self.verts = []
+
+    def plane(self, point, normal, mat):
+        """PlaneObject(point, normal, material): the constructor normalises the normal
+        (reference inc/RTObjects.h:167-172)."""
+        n = np.asarray(normal, dtype=np.float64)
+        n = n / np.sqrt(np.dot(n, n))
+        self.prims.append([PRIM_PLANE, mat, [*map(float, point), *map(float, n), 0.0, 0.0], 0, 0, 0])
+
+    def cube(self, center, half_size, mat):
+        """CubeObject(halfSize, material) at `center` (reference inc/RTObjects.h:543-549)."""
+        self.prims.append([PRIM_CUBE, mat, [*map(float, center), *map(float, half_size), 0.0, 0.0], 0, 0, 0])
+
+    def polygon(self, vertices, mat):
+        """PolygonObject(vertices, material): normal from the first three vertices, centroid = vertex mean
+        (computeNormalAndCentroid, reference inc/RTObjects.h:413-442; the mean is scaled in float there)."""
+        v = np.asarray(vertices, dtype=np.float32).astype(np.float64)
+        c = v.sum(axis=0) * np.float64(np.float32(1.0) / np.float32(len(v)))
+        if len(v) >= 3:
+            n = np.cross(v[1] - v[0], v[2] - v[0])
+            n = n / np.sqrt(np.dot(n, n))
+        else:
+            n = np.array([0.0, 0.0, 1.0])
+        first = len(self.verts)
+        self.verts.extend(v.tolist())
+        self.prims.append([PRIM_POLYGON, mat, [*n, *c, 0.0, 0.0], first, len(v), 0])
+
+    def select(self, prim_index, flag=True):
+        """Primitives::setSelectFlag (reference inc/RTObjects.h:79)."""
+        self.prims[prim_index][5] = 1 if flag else 0
 
     def light(self, position, ambient, diffuse, specular, view_pow):
         self.lights.append((tuple(position), tuple(ambient), tuple(diffuse), tuple(specular), float(view_pow)))
@@ -81,6 +121,8 @@ class _Builder:
     def sphere(self, center, radius, mat):
         self.sph.append((float(center[0]), float(center[1]), float(center[2]), float(radius)))
         self.mid.append(mat)
+        self.prims.append([PRIM_SPHERE, mat, [float(center[0]), float(center[1]), float(center[2]), float(radius),
+                                              0.0, 0.0, 0.0, 0.0], 0, 0, 0])
 
     def build(self, name, camera) -> Scene:
         spheres = np.array(self.sph, dtype=np.float32).reshape(-1, 4).view(SPHERE_DTYPE).reshape(-1)
@@ -100,7 +142,17 @@ class _Builder:
             lights[i]["diffuse"] = dif
             lights[i]["specular"] = spec
             lights[i]["view_pow"] = vp
-        return Scene(name, spheres, np.array(self.mid, dtype=np.uint32), mats, camera, lights)
+        prims = np.zeros(len(self.prims), dtype=PRIM_DTYPE)
+        for i, (t, m, pp, fv, nv, sel) in enumerate(self.prims):
+            prims[i]["type"] = t
+            prims[i]["mat"] = m
+            prims[i]["p"] = pp
+            prims[i]["first_vertex"] = fv
+            prims[i]["n_vertices"] = nv
+            prims[i]["selected"] = sel
+        verts = np.array(self.verts, dtype=np.float32).reshape(-1, 3)
+        general = any(pr[0] != PRIM_SPHERE or pr[5] for pr in self.prims)
+        return Scene(name, spheres, np.array(self.mid, dtype=np.uint32), mats, camera, lights, prims, verts, general)
 
 
 def small_scene(bubble: bool = False, light: bool = False, phong: int = 0) -> Scene:
@@ -124,6 +176,32 @@ def small_scene(bubble: bool = False, light: bool = False, phong: int = 0) -> Sc
     if phong >= 2:
         b.light((-3.0, 1.0, 4.5), (0.0, 0.0, 0.02), (0.2, 0.3, 0.5), (1.0, 1.0, 1.0), 4.0)
     return b.build("small", make_camera((0, 0, 0), (0, 0, 1)))
+
+
+def mixed_scene(selected: bool = False, phong: int = 0) -> Scene:
+    """Every primitive kind of the reference in one scene: a ground plane, an axis-aligned box, a quad and a
+    triangle, and spheres of three materials, in front of the default camera (+z, world-up +y)."""
+    b = _Builder()
+    ground = b.lambertian((0.6, 0.6, 0.5))
+    blue = b.lambertian((0.1, 0.2, 0.5))
+    gold = b.metal((0.8, 0.6, 0.2), 0.1)
+    glass = b.dielectric((1.0, 1.0, 1.0), 1.5)
+    red = b.lambertian((0.7, 0.15, 0.1))
+    green = b.lambertian((0.2, 0.6, 0.2))
+    b.plane((0.0, -0.5, 0.0), (0.0, 1.0, 0.0), ground)                       # 0
+    b.sphere((0.0, 0.0, 3.0), 0.5, blue)                                      # 1
+    b.cube((-1.3, -0.1, 3.2), (0.4, 0.4, 0.4), gold)                          # 2
+    b.sphere((1.1, 0.0, 2.8), 0.5, glass)                                     # 3
+    b.polygon([(-2.0, -0.5, 5.0), (2.0, -0.5, 5.0), (2.0, 1.5, 5.0), (-2.0, 1.5, 5.0)], red)   # 4: back wall quad
+    b.polygon([(0.2, 0.6, 2.2), (0.9, 0.9, 2.4), (0.5, 1.3, 2.6)], green)    # 5: floating triangle
+    b.cube((0.3, -0.3, 1.8), (0.15, 0.2, 0.15), glass)                        # 6: small glass box
+    if selected:
+        b.select(1)
+        b.select(2)
+        b.select(5)
+    if phong >= 1:
+        b.light((2.0, 3.0, 1.0), (0.05, 0.05, 0.05), (0.6, 0.6, 0.5), (1.0, 1.0, 1.0), 16.0)
+    return b.build("mixed", make_camera((0, 0, 0), (0, 0, 1)))
 
 
 class _Lcg:
@@ -198,6 +276,12 @@ def by_name(name: str) -> Scene:
         return small_scene(light=True)
     if name == "small_phong":
         return small_scene(phong=2)
+    if name == "mixed":
+        return mixed_scene()
+    if name == "mixed_selected":
+        return mixed_scene(selected=True)
+    if name == "mixed_lit":
+        return mixed_scene(selected=True, phong=1)
     if name == "random_spheres":
         return random_spheres_scene()
     if name == "grid10k":

@@ -470,3 +470,127 @@ def test_gpu_direct_light_kats(renderer):
         _, acc, rays = renderer.render_host(RenderParams(N, N, 1, 1, seed=1, flags=FLAG_DIRECT_LIGHT), want_accum=True)
         assert np.allclose(acc[N // 2, N // 2, :3], case["rgb"], atol=0.02), case["name"]
         assert rays == 2 * N * N
+
+
+# ---- planes, cubes, polygons and the selection halo -----------------------------------------------
+
+@pytest.mark.parametrize("scene_name", ["mixed", "mixed_selected"])
+@pytest.mark.parametrize("expanded_state", [False, True])
+def test_general_first_hit_refined_is_exact(renderer, oracle64, scene_name, expanded_state):
+    """Primary and bounced rays against every primitive kind: ids, halo flags and face flags equal the
+    double-precision oracle's bit for bit; t and normals agree to 1e-5."""
+    scene = scenes.by_name(scene_name)
+    renderer.set_scene(scene)
+    W, H = 320, 180
+    org, dirs = oracle64.primary_rays(scene.camera, W, H)
+    rng = np.random.default_rng(5)
+    # bounced rays: start on the first hits, random directions (unnormalised, as scatter makes them)
+    oid0, ot0, *_ = oracle64.first_hit(scene, org, dirs, tmin=TMIN, general=True)
+    hit0 = oid0 >= 0
+    o2 = (org + dirs * ot0[:, None])[hit0].astype(np.float32)
+    d2 = rng.normal(size=o2.shape).astype(np.float32) * rng.uniform(0.2, 3.0, size=(len(o2), 1)).astype(np.float32)
+    org = np.concatenate([org, o2])
+    dirs = np.concatenate([dirs, d2])
+    ids, t, nrm, front, exp = renderer.first_hit(org, dirs, tmin=TMIN, refine=True, expanded_state=expanded_state,
+                                                 want_expanded=True)
+    oid, ot, onrm, ofront, _, oexp = oracle64.first_hit(scene, org, dirs, tmin=TMIN, general=True,
+                                                        expanded_state=expanded_state, want_expanded=True)
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(exp, oexp)
+    hit = oid >= 0
+    assert np.array_equal(front[hit], ofront[hit])
+    assert np.all(np.abs(t[hit] - ot[hit]) <= 1e-5 * np.abs(ot[hit]) + 1e-7)
+    assert np.max(np.abs(nrm[hit] - onrm[hit])) <= 1e-5
+    kinds = set(scene.prims["type"][oid[hit]].tolist())
+    assert kinds == {0, 1, 2, 3}, kinds  # the rays met spheres, planes, cubes and polygons
+    if scene_name == "mixed_selected":
+        assert (exp.sum() > 0) == expanded_state
+
+
+@pytest.mark.parametrize("scene_name", ["mixed", "mixed_selected"])
+def test_general_first_hit_fp32_matches_except_ambiguous(renderer, oracle64, scene_name):
+    """The single-precision path (what the render kernel runs) picks the same primitive except on rays
+    that graze an edge or tie within rounding."""
+    scene = scenes.by_name(scene_name)
+    renderer.set_scene(scene)
+    W, H = 320, 180
+    org, dirs = oracle64.primary_rays(scene.camera, W, H)
+    ids, t, nrm, front, exp = renderer.first_hit(org, dirs, tmin=TMIN, expanded_state=True, want_expanded=True)
+    oid, ot, onrm, ofront, _, oexp = oracle64.first_hit(scene, org, dirs, tmin=TMIN, general=True, expanded_state=True,
+                                                        want_expanded=True)
+    same = ids == oid
+    assert same.mean() >= 0.999, same.mean()
+    assert (exp[same] == oexp[same]).mean() >= 0.9999
+    hit = same & (oid >= 0)
+    assert np.all(np.abs(t[hit] - ot[hit]) <= 2e-4 * np.abs(ot[hit]) + 1e-6)
+    ok = hit & (front == ofront)
+    assert ok.sum() >= 0.999 * hit.sum()
+    assert np.percentile(np.abs(nrm[ok] - onrm[ok]).max(axis=1), 99.9) <= 1e-3
+
+
+@pytest.mark.parametrize("scene_name,depth,lit", [("mixed", 10, False), ("mixed_selected", 10, False),
+                                                  ("mixed_selected", 1, False), ("mixed_lit", 6, True)])
+def test_general_render_matches_oracle(renderer, oracle64, scene_name, depth, lit):
+    from raytracer_amd.api import FLAG_DIRECT_LIGHT
+
+    scene = scenes.by_name(scene_name)
+    renderer.set_scene(scene)
+    W, H, spp = 160, 90, 128
+    p = RenderParams(W, H, samples_per_pixel=spp, max_depth=depth, seed=33, flags=FLAG_DIRECT_LIGHT if lit else 0)
+    rgba, accum, rays = renderer.render_host(p, want_accum=True)
+    ra, acc_a, rays_a = oracle64.render(scene, W, H, spp, depth, seed=33, direct_light=lit, general=True)
+    rb, _, _ = oracle64.render(scene, W, H, spp, depth, seed=34, direct_light=lit, general=True)
+    got, floor = psnr(rgba[:, :, :3], ra[:, :, :3]), psnr(ra[:, :, :3], rb[:, :, :3])
+    print(f"{scene_name} depth={depth} lit={lit}: PSNR(gpu,cpu)={got:.2f} dB, floor={floor:.2f} dB, "
+          f"rays {rays} vs {rays_a}")
+    assert got >= floor - 0.5
+    bias = (rgba[:, :, :3].astype(np.float64) - ra[:, :, :3]).mean(axis=(0, 1))
+    assert np.max(np.abs(bias)) <= 0.3
+    lin = accum[:, :, :3].astype(np.float64).mean(axis=(0, 1)) / spp
+    assert np.allclose(lin, acc_a.mean(axis=(0, 1)) / spp, rtol=5e-3)
+    assert abs(rays - rays_a) <= 0.004 * rays_a
+    if scene_name == "mixed_selected":
+        # pixels whose centre ray meets a halo shell first are tinted by the red emission
+        org, dirs = oracle64.primary_rays(scene.camera, W, H)
+        *_, oexp = oracle64.first_hit(scene, org, dirs, tmin=TMIN, general=True, expanded_state=True,
+                                      want_expanded=True)
+        halo = oexp.reshape(H, W).astype(bool)
+        assert halo.sum() > 20
+        # (the shell is thin: a pixel holds halo and non-halo samples, so the test is on the mean)
+        assert rgba[halo][:, 0].mean() > rgba[halo][:, 1].mean() + 40
+        assert np.abs(rgba[halo][:, :3].astype(int) - ra[halo][:, :3].astype(int)).max() <= 3
+
+
+def test_general_upload_of_spheres_only_equals_plain_upload(renderer):
+    """The same spheres through rt_upload_scene_ex render the same bytes as through rt_upload_scene."""
+    scene = scenes.small_scene(bubble=True)
+    p = RenderParams(96, 54, samples_per_pixel=16, max_depth=8, seed=3)
+    renderer.set_scene(scene)
+    a, _, rays_a = renderer.render_host(p)
+    renderer.upload_scene_ex(scene.prims, scene.verts, scene.mats)
+    b, _, rays_b = renderer.render_host(p)
+    assert np.array_equal(a, b) and rays_a == rays_b
+
+
+def test_general_upload_errors(renderer):
+    from raytracer_amd.api import PRIM_DTYPE, RtError
+
+    scene = scenes.by_name("mixed")
+    bad = scene.prims.copy()
+    bad[0]["type"] = 9
+    with pytest.raises(RtError, match="-3"):
+        renderer.upload_scene_ex(bad, scene.verts, scene.mats)
+    bad = scene.prims.copy()
+    bad[0]["mat"] = 1000
+    with pytest.raises(RtError, match="-1"):
+        renderer.upload_scene_ex(bad, scene.verts, scene.mats)
+    bad = scene.prims.copy()
+    poly = np.flatnonzero(bad["type"] == 3)[0]
+    bad[poly]["n_vertices"] = 10_000
+    with pytest.raises(RtError, match="-1"):
+        renderer.upload_scene_ex(bad, scene.verts, scene.mats)
+    # an empty general scene renders the sky
+    renderer.upload_scene_ex(np.zeros(0, dtype=PRIM_DTYPE), None, scene.mats)
+    renderer.set_camera(scene.camera)
+    rgba, _, rays = renderer.render_host(RenderParams(16, 8, 2, 5, seed=1))
+    assert rays == 16 * 8 * 2 and rgba[:, :, 2].min() > 200
