@@ -1,15 +1,15 @@
 // Camera.h — the render driver with the reference's interface (reference inc/Camera.h:10-137).
 // Camera::render keeps its signature; underneath it flattens the SceneManager into the plain
-// arrays of include/rt_amd.h and calls the HIP library (rt_upload_scene / rt_set_camera /
-// rt_render_host).  There is no CPU rendering path here.
+// arrays of include/rt_amd.h and calls the HIP library (rt_upload_scene_ex / rt_upload_lights /
+// rt_set_camera / rt_render_host).  There is no CPU rendering path here.
 #ifndef RTAMD_CAMERA_H
 #define RTAMD_CAMERA_H
 
 #include <cstdint>
-#include <stdexcept>
 #include <utility>
 #include <vector>
 
+#include "Backend.h"
 #include "RTGeometry.h"
 #include "RTObjects.h"
 
@@ -40,18 +40,6 @@ struct Viewport {
     gm::IVec3f rightDir_;
     gm::IVec3f downDir_;
     gm::IVec2f viewAngle_;
-};
-
-// Thrown by Camera::render when the scene uses something outside the accelerated path
-// (selected objects, a non-sphere primitive) or a HIP call fails.
-// The reference itself only asserts (src/Camera.cpp:76).
-class BackendError : public std::runtime_error {
-public:
-    BackendError(int status, const std::string &what) : std::runtime_error(what), status_(status) {}
-    int status() const { return status_; }
-
-private:
-    int status_;
 };
 
 class Camera {

@@ -16,6 +16,21 @@ struct Ray {
     gm::IPoint3 at(double t) const { return origin + direction * t; }
 };
 
+struct RTMaterial;
+class Primitives;
+
+// What a closest-hit query reports (reference inc/RTGeometry.h:49-62).  `object` is null for cubes
+// and polygons, as in the reference (inc/RTObjects.h:507,642).
+struct HitRecord {
+    gm::IPoint3 point = {};
+    gm::IVec3f normal = {};
+    const RTMaterial *material = nullptr;
+    const Primitives *object = nullptr;
+    bool frontFace = false;
+    double time = 0;
+    bool hitExpanded = false;
+};
+
 struct Interval {
     double min, max;
     Interval() : min(+std::numeric_limits<double>::infinity()), max(-std::numeric_limits<double>::infinity()) {}

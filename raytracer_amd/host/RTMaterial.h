@@ -1,12 +1,15 @@
 // RTMaterial.h — host-side materials with the reference's names and factory
-// (reference inc/RTMaterial.h:12-61, 63-96, 98-133, 135-198, 200-221, 223-248).
-// scatter() itself runs on the GPU; these classes carry the parameters and add the const
+// (reference inc/RTMaterial.h:12-61, 63-96, 98-133, 135-198, 200-221, 223-280).
+// scatter() itself runs on the GPU; these classes carry the parameters, the text
+// (de)serialisation (dump / scan / deserializeMaterial, :40-57,122-132,177-190,250-272) and the const
 // getters the reference lacks for its private members (RTMetal::fuzz_ :100,
 // RTDielectric::specular_local_ / refractionIndex_ :136-137), which the flattener needs.
 #ifndef RTAMD_RTMATERIAL_H
 #define RTAMD_RTMATERIAL_H
 
+#include <istream>
 #include <memory>
+#include <ostream>
 #include <string>
 #include <vector>
 
@@ -37,6 +40,26 @@ struct RTMaterial {
     const gm::IVec3f &diffuse() const { return diffuse_; }
     const gm::IVec3f &specular() const { return specular_; }
     const gm::IVec3f &emitted() const { return emission_; }
+
+protected:
+    // "Type d d d s s s e e e", then the fields of the subclass (reference :40-46)
+    virtual std::ostream &dump(std::ostream &os) const {
+        return os << typeString() << ' ' << diffuse_.x() << ' ' << diffuse_.y() << ' ' << diffuse_.z() << ' '
+                  << specular_.x() << ' ' << specular_.y() << ' ' << specular_.z() << ' ' << emission_.x() << ' '
+                  << emission_.y() << ' ' << emission_.z();
+    }
+    // reads what dump wrote after the type word (:48-57)
+    virtual std::istream &scan(std::istream &is) {
+        float v[9];
+        for (float &f : v) is >> f;
+        diffuse_ = gm::IVec3f(v[0], v[1], v[2]);
+        specular_ = gm::IVec3f(v[3], v[4], v[5]);
+        emission_ = gm::IVec3f(v[6], v[7], v[8]);
+        return is;
+    }
+
+    friend inline std::ostream &operator<<(std::ostream &os, const RTMaterial &m);
+    friend inline std::istream &operator>>(std::istream &is, RTMaterial &m);
 };
 
 class RTLambertian : public RTMaterial {
@@ -57,6 +80,17 @@ public:
     std::string typeString() const override { return "Metal"; }
     bool hasSpecular() const override { return true; }
     double fuzz() const { return fuzz_; }
+
+protected:
+    std::ostream &dump(std::ostream &os) const override {
+        RTMaterial::dump(os);
+        return os << ' ' << fuzz_;
+    }
+    // the scanned fuzz is taken as written, without the constructor's clamp (reference :128-132)
+    std::istream &scan(std::istream &is) override {
+        RTMaterial::scan(is);
+        return is >> fuzz_;
+    }
 };
 
 class RTDielectric : public RTMaterial {
@@ -71,6 +105,20 @@ public:
     bool hasSpecular() const override { return true; }
     const gm::IVec3f &tint() const { return specular_local_; } // the attenuation scatter() returns (:147)
     double refractionIndex() const { return refractionIndex_; }
+
+protected:
+    std::ostream &dump(std::ostream &os) const override {
+        RTMaterial::dump(os);
+        return os << ' ' << specular_local_.x() << ' ' << specular_local_.y() << ' ' << specular_local_.z() << ' '
+                  << refractionIndex_;
+    }
+    std::istream &scan(std::istream &is) override {
+        RTMaterial::scan(is);
+        float sx, sy, sz;
+        is >> sx >> sy >> sz >> refractionIndex_;
+        specular_local_ = gm::IVec3f(sx, sy, sz);
+        return is;
+    }
 };
 
 class RTEmissive : public RTMaterial {
@@ -102,7 +150,28 @@ public:
         children.push_back(std::make_unique<RTEmissive>(emission));
         return children.back().get();
     }
+
+    // Reads "Type fields..." as written by operator<<; nullptr for an unknown type word
+    // (reference :250-272).
+    RTMaterial *deserializeMaterial(std::istream &iss);
 };
+
+inline std::ostream &operator<<(std::ostream &os, const RTMaterial &m) { return m.dump(os); }
+inline std::istream &operator>>(std::istream &is, RTMaterial &m) { return m.scan(is); }
+
+inline RTMaterial *RTMaterialManager::deserializeMaterial(std::istream &iss) {
+    std::string type;
+    iss >> type;
+    std::unique_ptr<RTMaterial> mat;
+    if (type == "Lambertian") mat = std::make_unique<RTLambertian>(gm::IVec3f{});
+    else if (type == "Metal") mat = std::make_unique<RTMetal>(gm::IVec3f{}, 0.0);
+    else if (type == "Dielectric") mat = std::make_unique<RTDielectric>(gm::IVec3f{}, 1.0);
+    else if (type == "Emissive") mat = std::make_unique<RTEmissive>(gm::IVec3f{});
+    else return nullptr;
+    iss >> *mat;
+    children.push_back(std::move(mat));
+    return children.back().get();
+}
 
 } // namespace rtamd
 #endif

@@ -1,11 +1,14 @@
 // RayTracer.h — SceneManager, the scene container (reference inc/RayTracer.h:8-33,
-// src/RayTracer.cpp:8-66).  hitClosest (src/RayTracer.cpp:68-100) runs on the GPU; what stays
-// here is ownership and insertion order, which is the object id and the tie-break order.
+// src/RayTracer.cpp:8-66).  What stays on the host is ownership and insertion order, which is
+// the object id and the tie-break order; hitClosest (src/RayTracer.cpp:68-100) keeps its
+// signature and runs on the GPU.
 #ifndef RTAMD_RAYTRACER_H
 #define RTAMD_RAYTRACER_H
 
 #include <vector>
 
+#include "Backend.h"
+#include "RTGeometry.h"
 #include "RTObjects.h"
 
 namespace rtamd {
@@ -13,6 +16,8 @@ namespace rtamd {
 class SceneManager {
     std::vector<Primitives *> primitives_;
     std::vector<Light *> directLightSources_;
+    mutable rt_ctx *ctx_ = nullptr; // created by the first hitClosest
+    mutable int ctxDevice_ = -1;
 
 public:
     SceneManager() = default;
@@ -26,6 +31,17 @@ public:
     void addObject(Primitives *object);
     void addLight(Light *light);
     void clear();
+
+    // Closest hit of one ray, with the reference's signature and record (src/RayTracer.cpp:68-100):
+    // the scene is flattened and uploaded on every call and one ray is traced on the GPU with the
+    // double-precision refinement on, so the primitive picked is the one a double evaluation picks.
+    // Meant for picking (a mouse click), not for loops: use the batch form for many rays.
+    // Throws BackendError when no GPU is usable or the scene holds an unknown primitive kind.
+    bool hitClosest(const Ray &ray, Interval rayTime, HitRecord &hitRecord, bool hitExpandedState) const;
+    // Batch form (not in the reference): one upload, one launch; hit[i] tells whether records[i] is a hit.
+    void hitClosest(const std::vector<Ray> &rays, Interval rayTime, bool hitExpandedState,
+                    std::vector<HitRecord> &records, std::vector<char> &hit) const;
+    int device = 0; // which GPU hitClosest uses (not in the reference)
 
     const std::vector<Light *> &inderectLightSources() const { return directLightSources_; }
     std::vector<Primitives *> &primitives() { return primitives_; }

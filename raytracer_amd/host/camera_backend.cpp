@@ -1,11 +1,10 @@
 // Camera: pose / viewport on the host (reference src/Camera.cpp:38-52, 206-236) and
 // render() as a client of the HIP library's C ABI (include/rt_amd.h).
 #include <cmath>
-#include <map>
 #include <ostream>
 #include <string>
 
-#include "../../include/rt_amd.h"
+#include "Backend.h"
 #include "Camera.h"
 #include "RayTracer.h"
 
@@ -79,46 +78,8 @@ void Camera::render(const SceneManager &sceneManager, const std::pair<int, int> 
     if ((size_t)W * (size_t)H != outputBufer.size())
         throw BackendError(RT_ERR_INVALID, "Camera::render: outputBufer.size() != width*height");
 
-    // ---- flatten: spheres in insertion order, materials de-duplicated by pointer ----
-    std::vector<rt_sphere> spheres;
-    std::vector<uint32_t> matId;
-    std::vector<rt_material> mats;
-    std::map<const RTMaterial *, uint32_t> seen;
-    for (const Primitives *p : sceneManager.primitives()) {
-        const SphereObject *s = dynamic_cast<const SphereObject *>(p);
-        if (!s) throw BackendError(RT_ERR_UNSUPPORTED, "Camera::render: primitive '" + p->typeString() +
-                                                           "' is outside the GPU path (spheres only)");
-        if (p->selected())
-            throw BackendError(RT_ERR_UNSUPPORTED, "Camera::render: selected objects (halo) are outside the GPU path");
-        const RTMaterial *m = p->material();
-        if (!m) throw BackendError(RT_ERR_INVALID, "Camera::render: primitive without material");
-        auto it = seen.find(m);
-        if (it == seen.end()) {
-            rt_material fm{};
-            fm.type = (uint32_t)m->kind();
-            gm::IVec3f albedo;
-            switch (m->kind()) {
-            case RTMaterialKind::Lambertian: albedo = m->diffuse(); break;
-            case RTMaterialKind::Metal:
-                albedo = m->specular();
-                fm.fuzz = (float)static_cast<const RTMetal *>(m)->fuzz();
-                break;
-            case RTMaterialKind::Dielectric:
-                albedo = static_cast<const RTDielectric *>(m)->tint();
-                fm.ior = (float)static_cast<const RTDielectric *>(m)->refractionIndex();
-                break;
-            case RTMaterialKind::Emissive: break;
-            }
-            put3(fm.albedo, albedo);
-            put3(fm.emission, m->emitted());
-            put3(fm.diffuse, m->diffuse()); // what Light::getDirectLighting multiplies by
-            it = seen.emplace(m, (uint32_t)mats.size()).first;
-            mats.push_back(fm);
-        }
-        gm::IPoint3 c = p->position();
-        spheres.push_back(rt_sphere{(float)c.x(), (float)c.y(), (float)c.z(), s->getRadius()});
-        matId.push_back(it->second);
-    }
+    // flatten first: a scene the GPU path cannot take is rejected before any device is touched
+    const FlatScene flat = flattenScene(sceneManager, renderProperties.enableLDirect);
 
     if (!ctx_ || ctxDevice_ != device) {
         if (ctx_) rt_destroy(ctx_);
@@ -127,31 +88,14 @@ void Camera::render(const SceneManager &sceneManager, const std::pair<int, int> 
         if (rc != RT_OK) throw BackendError(rc, "rt_create failed (no usable GPU?)");
         ctxDevice_ = device;
     }
-    int rc = rt_upload_scene(ctx_, (int)spheres.size(), spheres.data(), matId.data(), (int)mats.size(), mats.data());
-    if (rc != RT_OK) fail(ctx_, rc, "rt_upload_scene");
-
-    // lights feed Camera::computeDirectLighting (reference src/Camera.cpp:161-178) when enableLDirect is set
-    std::vector<rt_light> lights;
-    if (renderProperties.enableLDirect) {
-        for (const Light *l : sceneManager.lights()) {
-            rt_light fl{};
-            put3(fl.position, l->position());
-            put3(fl.ambient, l->ambientIntensity());
-            put3(fl.diffuse, l->defuseIntensity());
-            put3(fl.specular, l->specularIntensity());
-            fl.view_pow = (float)l->viewLightPow();
-            lights.push_back(fl);
-        }
-    }
-    rc = rt_upload_lights(ctx_, (int)lights.size(), lights.data());
-    if (rc != RT_OK) fail(ctx_, rc, "rt_upload_lights");
+    uploadScene(ctx_, flat);
 
     rt_camera cam{};
     put3(cam.center, center_);
     put3(cam.upper_left, viewPort_.upperLeft_);
     put3(cam.right, viewPort_.rightDir_);
     put3(cam.down, viewPort_.downDir_);
-    rc = rt_set_camera(ctx_, &cam);
+    int rc = rt_set_camera(ctx_, &cam);
     if (rc != RT_OK) fail(ctx_, rc, "rt_set_camera");
 
     rt_params p{};
@@ -161,7 +105,8 @@ void Camera::render(const SceneManager &sceneManager, const std::pair<int, int> 
     p.samples_per_pixel = renderProperties.samplesPerPixel * sps;
     p.max_depth = renderProperties.maxRayDepth;
     p.seed = seed;
-    p.flags = lights.empty() ? 0u : (uint32_t)RT_FLAG_DIRECT_LIGHT;
+    // lights feed Camera::computeDirectLighting (reference src/Camera.cpp:161-178) when enableLDirect is set
+    p.flags = flat.lights.empty() ? 0u : (uint32_t)RT_FLAG_DIRECT_LIGHT;
     p.strip_first = 0;
     p.strip_stride = 1;
     static_assert(sizeof(RTPixelColor) == 4, "RTPixelColor must be 4 bytes of RGBA");

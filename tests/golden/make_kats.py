@@ -130,6 +130,85 @@ kats["direct_light"] = dict(
     ],
 )
 
+# ---- the other primitive kinds and the selection halo, through hitClosest ------------------------
+# (PlaneObject::hit inc/RTObjects.h:174-190, CubeObject::hitBox :586-644, PolygonObject::hitDetail :469-512,
+#  hitExpanded :96-105/:370-386/:560-568, SceneManager::hitClosest src/RayTracer.cpp:68-100)
+# prim specs: ["sphere", centre, r] | ["plane", point, normal] | ["cube", centre, half] | ["polygon", vertices];
+# "selected" lists the selected indices.  Each ray: expanded_state -> id, t, unit normal, front, expanded.
+# normal/front follow HitRecord::setFaceNormal: front = dot(d, outward) < 0, normal faces against the ray.
+#   plane: "outward" is first turned ALONG the ray (:184-185), so front is always false and the reported
+#          normal is the plane normal turned against the ray
+#   polygon: outward is turned against the ray (:502-503), so front is always true
+SQ = [[-1, -1, 4], [1, -1, 4], [1, 1, 4], [-1, 1, 4]]     # unit normal (2,0,0)x(2,2,0) = +z, centroid (0,0,4)
+TRI = [[2, 0, 0], [2, 2, 0], [2, 0, 2]]                   # in the plane x = 2: (0,2,0)x(0,0,2) = +x
+H105 = math.sqrt(1.05 ** 2 - 1.02 ** 2)                   # half chord of the r = 1.05 shell at offset 1.02
+kats["prims"] = [
+    dict(name="plane y = -1", prims=[["plane", [0, -1, 0], [0, 1, 0]]], selected=[], rays=[
+        dict(o=[0, 0, 0], d=[0, -1, 0], es=0, id=0, t=1.0, n=[0, 1, 0], front=0, exp=0),     # (-1)/(-1)
+        dict(o=[0, -3, 0], d=[0, 2, 0], es=0, id=0, t=1.0, n=[0, -1, 0], front=0, exp=0),    # from below: 2/2
+        dict(o=[0, 0, 0], d=[1, 0, 0], es=0, id=-1),                                         # parallel: -1 * inf
+        dict(o=[0, 0, 0], d=[0, 1, 0], es=0, id=-1),                                         # behind: t = -1
+        dict(o=[0, 1, 0], d=[0.6, -0.8, 0], es=0, id=0, t=2.5, n=[0, 1, 0], front=0, exp=0), # (-2)/(-0.8)
+        dict(o=[0, 1, 0], d=[0.6, -0.8, 0], es=1, id=0, t=2.5, n=[0, 1, 0], front=0, exp=0), # halo pass: same hit
+    ]),
+    dict(name="cube centre (0,0,5), half (1,2,0.5)", prims=[["cube", [0, 0, 5], [1, 2, 0.5]]], selected=[], rays=[
+        dict(o=[0, 0, 0], d=[0, 0, 1], es=0, id=0, t=4.5, n=[0, 0, -1], front=1, exp=0),     # near z face
+        dict(o=[0, 0, 0], d=[0, 0, 2], es=0, id=0, t=2.25, n=[0, 0, -1], front=1, exp=0),    # |d| = 2 halves t
+        dict(o=[0, 0, 5], d=[1, 0, 0], es=0, id=0, t=1.0, n=[-1, 0, 0], front=0, exp=0),     # from inside: exit face
+        dict(o=[3, 0, 0], d=[0, 0, 1], es=0, id=-1),                                         # outside the x slab
+        dict(o=[0, 0, 0], d=[0, 0, -1], es=0, id=-1),                                        # box behind the ray
+        # x slab [5, 7.5], z slab [4/0.6, 5/0.6]: entry through the z face at t = 20/3
+        dict(o=[-5, 0, 0.5], d=[0.8, 0, 0.6], es=0, id=0, t=20 / 3, n=[0, 0, -1], front=1, exp=0),
+        # x slab [5, 7.5], z slab [1/0.6, 2/0.6] lies before it: miss
+        dict(o=[-5, 0, 3.5], d=[0.8, 0, 0.6], es=0, id=-1),
+    ]),
+    dict(name="square in z = 4", prims=[["polygon", SQ]], selected=[], rays=[
+        dict(o=[0, 0, 0], d=[0, 0, 1], es=0, id=0, t=4.0, n=[0, 0, -1], front=1, exp=0),
+        dict(o=[0.5, 0.5, 6], d=[0, 0, -1], es=0, id=0, t=2.0, n=[0, 0, 1], front=1, exp=0),   # from behind
+        dict(o=[1.5, 0, 0], d=[0, 0, 1], es=0, id=-1),                                         # beside it
+        dict(o=[0, 0, 0], d=[1, 0, 0], es=0, id=-1),                                           # parallel
+        dict(o=[0, 0, 5], d=[0, 0, 1], es=0, id=-1),                                           # behind the ray
+    ]),
+    dict(name="triangle in x = 2 (projection drops x)", prims=[["polygon", TRI]], selected=[], rays=[
+        dict(o=[0, 0.5, 0.5], d=[1, 0, 0], es=0, id=0, t=2.0, n=[-1, 0, 0], front=1, exp=0),   # y + z = 1 < 2
+        dict(o=[0, 1.5, 1.5], d=[1, 0, 0], es=0, id=-1),                                       # y + z = 3 > 2
+    ]),
+    dict(name="tie between kinds: insertion order decides", prims=[["plane", [0, 0, 4], [0, 0, 1]],
+                                                                     ["sphere", [0, 0, 5], 1.0]], selected=[], rays=[
+        dict(o=[0, 0, 0], d=[0, 0, 1], es=0, id=0, t=4.0, n=[0, 0, -1], front=0, exp=0),
+    ]),
+    dict(name="same tie, sphere first", prims=[["sphere", [0, 0, 5], 1.0], ["plane", [0, 0, 4], [0, 0, 1]]],
+         selected=[], rays=[
+        dict(o=[0, 0, 0], d=[0, 0, 1], es=0, id=0, t=4.0, n=[0, 0, -1], front=1, exp=0),
+    ]),
+    dict(name="selected sphere in front of a plane", prims=[["sphere", [0, 0, 5], 1.0], ["plane", [0, 0, 10], [0, 0, -1]]],
+         selected=[0], rays=[
+        dict(o=[0, 0, 0], d=[0, 0, 1], es=1, id=0, t=4.0, n=[0, 0, -1], front=1, exp=0),     # the sphere itself
+        # passes the sphere at x = 1.02 but meets its 1.05 shell: outward = (1.02, 0, -h)/1.05
+        dict(o=[1.02, 0, 0], d=[0, 0, 1], es=1, id=0, t=5 - H105, n=[1.02 / 1.05, 0, -H105 / 1.05], front=1, exp=1),
+        dict(o=[1.02, 0, 0], d=[0, 0, 1], es=0, id=1, t=10.0, n=[0, 0, -1], front=0, exp=0), # no halo pass
+        dict(o=[1.06, 0, 0], d=[0, 0, 1], es=1, id=1, t=10.0, n=[0, 0, -1], front=0, exp=0), # past the shell
+    ]),
+    dict(name="same, nothing selected", prims=[["sphere", [0, 0, 5], 1.0], ["plane", [0, 0, 10], [0, 0, -1]]],
+         selected=[], rays=[
+        dict(o=[1.02, 0, 0], d=[0, 0, 1], es=1, id=1, t=10.0, n=[0, 0, -1], front=0, exp=0),
+    ]),
+    dict(name="halo hidden behind a nearer object", prims=[["sphere", [0, 0, 5], 1.0], ["plane", [0, 0, 3], [0, 0, -1]]],
+         selected=[0], rays=[
+        dict(o=[1.02, 0, 0], d=[0, 0, 1], es=1, id=1, t=3.0, n=[0, 0, -1], front=0, exp=0),
+    ]),
+    dict(name="selected cube", prims=[["cube", [0, 0, 5], [1, 1, 1]]], selected=[0], rays=[
+        dict(o=[1.02, 0, 0], d=[0, 0, 1], es=1, id=0, t=3.95, n=[0, 0, -1], front=1, exp=1), # grown half 1.05
+        dict(o=[1.02, 0, 0], d=[0, 0, 1], es=0, id=-1),
+        dict(o=[0.5, 0, 0], d=[0, 0, 1], es=1, id=0, t=4.0, n=[0, 0, -1], front=1, exp=0),
+    ]),
+    dict(name="selected square", prims=[["polygon", SQ]], selected=[0], rays=[
+        dict(o=[1.02, 0, 0], d=[0, 0, 1], es=1, id=0, t=4.0, n=[0, 0, -1], front=1, exp=1),  # vertices at +-1.05
+        dict(o=[1.02, 0, 0], d=[0, 0, 1], es=0, id=-1),
+        dict(o=[1.06, 0, 0], d=[0, 0, 1], es=1, id=-1),
+    ]),
+]
+
 # ---- random words: regression vector of the generator both sides share ------------------------
 # (pcg4d as written in oracle/rt_oracle.c; values produced by a straight Python transcription)
 def pcg4d(x, y, z, w):

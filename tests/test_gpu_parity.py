@@ -594,3 +594,17 @@ def test_general_upload_errors(renderer):
     renderer.set_camera(scene.camera)
     rgba, _, rays = renderer.render_host(RenderParams(16, 8, 2, 5, seed=1))
     assert rays == 16 * 8 * 2 and rgba[:, :, 2].min() > 200
+
+
+@pytest.mark.parametrize("refine", [True, False])
+def test_gpu_primitive_and_halo_kats(renderer, refine):
+    from tests.test_oracle import check_prim_kat
+
+    def first_hit(scene, org, dirs, es):
+        renderer.set_scene(scene)
+        return renderer.first_hit(org, dirs, tmin=0.001, refine=refine, expanded_state=es, want_expanded=True)
+
+    for case in KATS["prims"]:
+        if not refine and "tie" in case["name"]:
+            continue  # single precision may round the two equal distances apart
+        check_prim_kat(case, first_hit, 1e-6 if refine else 1e-5)

@@ -1,5 +1,5 @@
-"""The reference-shaped C++ host layer (raytracer_amd/host): Camera / SceneManager / SphereObject /
-RTMaterialManager above the C ABI.  The driver binary is built by __graft_entry__.build()."""
+"""The reference-shaped C++ host layer (raytracer_amd/host): Camera / SceneManager / the Primitives classes /
+RTMaterialManager / scene files above the C ABI.  The driver binaries are built by __graft_entry__.build()."""
 import json
 import os
 import subprocess
@@ -11,11 +11,12 @@ from raytracer_amd import scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEMO = os.path.join(ROOT, "raytracer_amd", "host", "tests", "host_demo.bin")
+RENDER_SCENE = os.path.join(ROOT, "raytracer_amd", "host", "tools", "render_scene.bin")
 KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kats.json")))
 
 
 def _need_demo():
-    if not os.path.exists(DEMO):
+    if not (os.path.exists(DEMO) and os.path.exists(RENDER_SCENE)):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "raytracer_amd", "host"), "-s"])
     return DEMO
 
@@ -38,11 +39,65 @@ def test_camera_pose_matches_kats_and_oracle(oracle64):
 
 
 def test_unsupported_scenes_are_rejected_not_rendered_differently():
-    """Selected objects and a short output buffer raise BackendError before any GPU work
-    (there is no CPU fallback to route them to)."""
+    """A short output buffer and a primitive kind the GPU path does not know (in Camera::render and in
+    SceneManager::hitClosest) raise BackendError before any GPU work: there is no CPU fallback to route them to."""
     out = subprocess.run([_need_demo(), "--unsupported"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "caught 2" in out.stdout
+    assert "caught 3" in out.stdout
+
+
+def test_scene_file_records_follow_the_reference_format(tmp_path):
+    """operator<< of Primitives / Light / RTMaterial (reference inc/RTObjects.h:39-47,114-118,202-209,267-275,
+    389-396,571-575; inc/RTMaterial.h:40-46,122-126,177-182): 'Type x y z selected fields...'."""
+    demo = _need_demo()
+    f = str(tmp_path / "scene.txt")
+    subprocess.check_call([demo, "--save", "mixed_selected", f])
+    lines = open(f).read().splitlines()
+    assert lines[0] == "Camera 0 0 0 0 0 1"
+    assert "Material Metal 0 0 0 0.8 0.6 0.2 0 0 0 0.1" in lines
+    assert "Material Dielectric 0 0 0 0 0 0 0 0 0 1 1 1 1.5" in lines
+    assert "Material Lambertian 0.1 0.2 0.5 0 0 0 0 0 0" in lines
+    assert "Object 0 Plane 0 -0.5 0 0 0 1 0" in lines
+    assert "Object 1 Sphere 0 0 3 1 0.5" in lines                 # selected
+    assert "Object 2 Cube -1.3 -0.1 3.2 1 0.4 0.4 0.4" in lines
+    assert "Object 4 Polygon 0 0.5 5 0 4 -2 -0.5 5 2 -0.5 5 2 1.5 5 -2 1.5 5" in lines   # position = centroid
+    subprocess.check_call([demo, "--save", "lit", f])
+    assert "Light 2 3 1 0.05 0.05 0.05 0.6 0.6 0.5 1 1 1 16" in open(f).read().splitlines()
+
+
+def test_scene_file_round_trip(tmp_path):
+    """load(save(scene)) keeps every number to single precision: saving the reloaded scene again, and
+    reloading that, reproduces the file byte for byte."""
+    demo = _need_demo()
+    a, b, c = (str(tmp_path / n) for n in ("a.txt", "b.txt", "c.txt"))
+    for name in ("mixed_selected", "lit"):
+        subprocess.check_call([demo, "--save", name, a])
+        subprocess.check_call([demo, "--resave", a, b])
+        subprocess.check_call([demo, "--resave", b, c])
+        assert open(b).read() == open(c).read()
+        va = np.array([float(x) for ln in open(a) for x in ln.split()[1:] if x[0] in "-0123456789"], np.float32)
+        vb = np.array([float(x) for ln in open(b) for x in ln.split()[1:] if x[0] in "-0123456789"], np.float32)
+        assert np.array_equal(va, vb)
+
+
+def test_scene_file_errors(tmp_path):
+    demo = _need_demo()
+    out = str(tmp_path / "out.txt")
+    for text, what in [("Object 0 Sphere 0 0 3 0 0.5\n", "material index"),
+                       ("Material Plastic 1 1 1\n", "unknown material"),
+                       ("Material Lambertian 0.5 0.5 0.5 0 0 0 0 0 0\nObject 0 Torus 0 0 0 0\n", "unknown primitive"),
+                       ("Material Lambertian 0.5 0.5 0.5 0 0 0 0 0 0\nObject 0 Sphere 0 0\n", "short primitive"),
+                       ("Light 1 2 3\n", "short light"),
+                       ("Banana 1\n", "unknown record")]:
+        f = str(tmp_path / "bad.txt")
+        open(f, "w").write(text)
+        r = subprocess.run([demo, "--resave", f, out], capture_output=True, text=True)
+        assert r.returncode == 1 and what in r.stderr, (text, r.stderr)
+    # comments and blank lines are skipped
+    f = str(tmp_path / "ok.txt")
+    open(f, "w").write("# a comment\n\nMaterial Emissive 0 0 0 0 0 0 4 4 4\nObject 0 Cube 0 1 2 0 1 1 1\n")
+    assert subprocess.run([demo, "--resave", f, out]).returncode == 0
+    assert "Object 0 Cube 0 1 2 0 1 1 1" in open(out).read()
 
 
 @pytest.mark.gpu
@@ -83,3 +138,59 @@ def test_camera_render_with_lights_matches_oracle(tmp_path, oracle64):
     assert np.mean(d * d) <= np.mean((other[:, :, :3].astype(float) - ref[:, :, :3]) ** 2)
     assert np.abs(d.mean(axis=(0, 1))).max() <= 0.25
     assert abs(int(r.stdout.strip().split()[-1]) - rays) <= 0.004 * rays
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mixed", "mixed_selected", "mixed_lit"])
+def test_camera_render_of_every_primitive_kind_matches_oracle(tmp_path, oracle64, name):
+    """PlaneObject / CubeObject / PolygonObject / selection through the host API, and the same scene
+    through a scene file: the file render equals the API render byte for byte."""
+    W, H, spp, depth = 160, 90, 64, 8
+    raw = str(tmp_path / "img.rgba")
+    ppm = str(tmp_path / "img.ppm")
+    r = subprocess.run([_need_demo(), raw, str(W), str(H), str(spp), str(depth), ppm, name], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = np.fromfile(raw, np.uint8).reshape(H, W, 4)
+    scene = scenes.by_name(name)
+    lit = name == "mixed_lit"
+    ref, _, rays = oracle64.render(scene, W, H, spp, depth, seed=21, direct_light=lit, general=True)
+    other, _, _ = oracle64.render(scene, W, H, spp, depth, seed=22, direct_light=lit, general=True)
+    d = img[:, :, :3].astype(float) - ref[:, :, :3]
+    assert np.mean(d * d) <= np.mean((other[:, :, :3].astype(float) - ref[:, :, :3]) ** 2)
+    assert np.abs(d.mean(axis=(0, 1))).max() <= 0.3
+    assert abs(int(r.stdout.strip().split()[-1]) - rays) <= 0.004 * rays
+    f = str(tmp_path / "scene.txt")
+    ppm2 = str(tmp_path / "file.ppm")
+    subprocess.check_call([_need_demo(), "--save", name, f])
+    r2 = subprocess.run([RENDER_SCENE, f, ppm2, str(W), str(H), str(spp), str(depth), "21"], capture_output=True,
+                        text=True)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert open(ppm, "rb").read() == open(ppm2, "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("expanded", [0, 1])
+def test_scene_manager_hit_closest_matches_oracle(oracle64, expanded):
+    """SceneManager::hitClosest (reference src/RayTracer.cpp:68-100) with its own signature, on the GPU."""
+    W, H = 64, 36
+    r = subprocess.run([_need_demo(), "--pick", "mixed_selected", str(W), str(H), str(expanded)], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = np.array([[float(x) for x in ln.split()] for ln in r.stdout.strip().splitlines()])
+    assert rows.shape == (W * H, 8)
+    scene = scenes.by_name("mixed_selected")
+    org, dirs = oracle64.primary_rays(scene.camera, W, H)
+    oid, ot, onrm, ofront, _, oexp = oracle64.first_hit(scene, org, dirs, tmin=0.001, general=True,
+                                                        expanded_state=bool(expanded), want_expanded=True)
+    hit = oid >= 0
+    assert np.array_equal(rows[:, 0].astype(bool), hit)
+    # HitRecord::object is null for cubes and polygons (reference inc/RTObjects.h:507,642)
+    kinds = scene.prims["type"][np.maximum(oid, 0)]
+    want_obj = np.where(hit & (kinds != 2) & (kinds != 3), oid, -1)
+    assert np.array_equal(rows[:, 1].astype(int), want_obj)
+    assert np.allclose(rows[hit, 2], ot[hit], rtol=1e-5)
+    assert np.allclose(rows[hit, 3:6], onrm[hit], atol=1e-5)
+    assert np.array_equal(rows[hit, 6].astype(int), ofront[hit])
+    assert np.array_equal(rows[:, 7].astype(int), oexp)
+    assert (oexp.sum() > 0) == bool(expanded)

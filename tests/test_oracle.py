@@ -170,3 +170,59 @@ def test_direct_light_kats(oracle64, case):
     _, acc, rays = oracle64.render(scene, N, N, 1, 1, seed=1, y0=N // 2, y1=N // 2 + 1, direct_light=True)
     assert np.allclose(acc[N // 2, N // 2], case["rgb"], atol=0.02)
     assert rays == 2 * N  # one primary + one shadow query per pixel of the row (every ray hits the ground)
+
+
+def prim_kat_scene(case):
+    """The scene of one entry of KATS["prims"]."""
+    b = scenes._Builder()
+    m = b.lambertian((0.5, 0.5, 0.5))
+    for spec in case["prims"]:
+        kind = spec[0]
+        if kind == "sphere":
+            b.sphere(spec[1], spec[2], m)
+        elif kind == "plane":
+            b.plane(spec[1], spec[2], m)
+        elif kind == "cube":
+            b.cube(spec[1], spec[2], m)
+        else:
+            b.polygon(spec[1], m)
+    for i in case["selected"]:
+        b.select(i)
+    scene = b.build("kat", scenes.make_camera())
+    scene.needs_general = True
+    return scene
+
+
+def check_prim_kat(case, first_hit, atol):
+    """first_hit(scene, org, dir, expanded_state) -> ids, t, normal, front, expanded"""
+    scene = prim_kat_scene(case)
+    for es in (0, 1):
+        rays = [r for r in case["rays"] if r["es"] == es]
+        if not rays:
+            continue
+        org = np.array([r["o"] for r in rays], dtype=np.float32)
+        dirs = np.array([r["d"] for r in rays], dtype=np.float32)
+        ids, t, nrm, front, exp = first_hit(scene, org, dirs, bool(es))
+        for k, r in enumerate(rays):
+            what = f'{case["name"]}: ray {r["o"]} -> {r["d"]} es={es}'
+            assert ids[k] == r["id"], what
+            if r["id"] < 0:
+                continue
+            assert abs(t[k] - r["t"]) <= atol * max(1.0, abs(r["t"])), what
+            assert np.allclose(nrm[k], r["n"], atol=atol), what
+            assert int(front[k]) == r["front"] and int(exp[k]) == r["exp"], what
+
+
+@pytest.mark.parametrize("case", KATS["prims"], ids=[c["name"] for c in KATS["prims"]])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_primitive_and_halo_kats(oracle64, oracle32, case, prec):
+    orc = oracle64 if prec == "f64" else oracle32
+
+    def first_hit(scene, org, dirs, es):
+        ids, t, nrm, front, _, exp = orc.first_hit(scene, org, dirs, tmin=0.001, general=True, expanded_state=es,
+                                                   want_expanded=True)
+        return ids, t, nrm, front, exp
+
+    if prec == "f32" and "tie" in case["name"]:
+        pytest.skip("an exact tie is a double-precision statement")
+    check_prim_kat(case, first_hit, 1e-6 if prec == "f64" else 1e-5)
