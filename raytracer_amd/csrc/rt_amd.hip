@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 #include <new>
+#include <cmath>
 
 #include "../../include/rt_amd.h"
 #include "rt_device.h"
@@ -35,8 +36,8 @@ namespace {
 constexpr int WG_THREADS = 256;
 constexpr int WAVES_PER_WG = 4;
 constexpr int MAX_TILE_PX = 256;             // largest pixel tile a work item may cover (32 x 8)
-constexpr int RESIDENT_MAX = 4096;           // spheres kept resident in LDS (64 KiB)
-constexpr int STREAM_QUADS = 512;            // quads (4 spheres, 64 B) per streamed LDS tile (32 KiB)
+constexpr int RESIDENT_MAX = 4096;           // spheres kept resident in LDS (80 KiB)
+constexpr int STREAM_QUADS = 512;            // quads (4 spheres, 80 B) per streamed LDS tile (40 KiB)
 constexpr size_t ACC_BYTES = WAVES_PER_WG * MAX_TILE_PX * 3 * sizeof(float); // LDS accumulators
 constexpr float TMIN = 0.001f;               // CLOSEST_HIT_MIN_T, src/Camera.cpp:10
 
@@ -47,10 +48,14 @@ struct KParams {
     int spp, max_depth, sample_offset;
     uint32_t seed, flags;
     int strip_first, strip_stride;
-    int tile_w_log2, tile_h_log2; // work-item tile: 4x4, 8x8 or 32x8 pixels
-    int tiles_x;         // tiles across the image
-    int tiles_per_strip; // tiles_x * (8 / tile height)
-    int n_items;         // tiles this call renders
+    // work-item tiles come in two sizes: the strips above image row `small_from_strip * 8` use the
+    // first shape, the strips below it (the end of the queue) the second, smaller one
+    int tile_w_log2[2], tile_h_log2[2];
+    int tiles_x[2];         // tiles across the image
+    int tiles_per_strip[2]; // tiles_x * (8 / tile height)
+    int n_items_big;        // items of the first shape this call renders
+    int n_strips_big;       // local strips of the first shape
+    int n_items;            // items this call renders
     int n_quads;     // sphere quads to scan (padding included)
     int n_lights;    // lights shaded at every hit (0 unless RT_FLAG_DIRECT_LIGHT)
     float inv_w, inv_h;
@@ -59,8 +64,9 @@ struct KParams {
 
 struct DeviceScene {
     const float4 *sph;    // cx, cy, cz, r
-    const float4 *pairs;  // pair-interleaved (centre, r^2) words, see rt_device.h; padded with
+    const float4 *pairs;  // pair-interleaved (centre, q) words, see rt_device.h; padded with
                           // never-hit spheres to a multiple of 8 plus four spare quads
+    const float4 *r2q;    // squared radii, one float4 per group of four spheres, padded alike
     const uint32_t *mat_id;
     const DMat *mats;
     const DLight *lights;
@@ -72,15 +78,15 @@ enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2 };
 
 // Scan `nquads` groups of four spheres held in LDS (every lane reads the same address:
 // a broadcast read) for one ray.
-__device__ __forceinline__ void scan_lds(const float4 *lds, int nquads, int base, const RayK &r, V3 o, V3 dh, float tmin,
-                                         int self_id, float &best_t, int &best_id) {
+__device__ __forceinline__ void scan_lds(const float4 *lds, const float4 *lds_r2, int nquads, int base, const RayK &r,
+                                         V3 o, V3 dh, float tmin, int self_id, float &best_t, int &best_id) {
 #ifndef RT_UNROLL
 #define RT_UNROLL 1
 #endif
 #pragma unroll RT_UNROLL
     for (int q = 0; q < nquads; ++q) {
         float4 A0 = lds[4 * q], B0 = lds[4 * q + 1], A1 = lds[4 * q + 2], B1 = lds[4 * q + 3];
-        test_quad(r, o, dh, A0, B0, A1, B1, tmin, base + 4 * q, self_id, best_t, best_id);
+        test_quad(r, o, dh, A0, B0, A1, B1, lds_r2[q], tmin, base + 4 * q, self_id, best_t, best_id);
     }
 }
 
@@ -91,6 +97,7 @@ __device__ __forceinline__ void scan_lds(const float4 *lds, int nquads, int base
 // order, so the only safe wait is lgkmcnt(0); the loop keeps exactly one load in
 // flight: wait for quad q, request quad q+1, test quad q.
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
 template <int BYTE_OFF>
 __device__ __forceinline__ u32x16 sload_quad(const float4 *p) {
@@ -98,42 +105,60 @@ __device__ __forceinline__ u32x16 sload_quad(const float4 *p) {
     asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "i"(BYTE_OFF) : "memory");
     return v;
 }
-__device__ __forceinline__ void swait_quads(u32x16 &a, u32x16 &b) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory");
+// squared radii of two consecutive quads
+template <int BYTE_OFF>
+__device__ __forceinline__ u32x8 sload_r2(const float4 *p) {
+    u32x8 v;
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(p), "i"(BYTE_OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void swait_quads(u32x16 &a, u32x16 &b, u32x8 &r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(r)::"memory");
 }
 __device__ __forceinline__ float4 word(const u32x16 &v, int k) {
     return make_float4(__uint_as_float(v[4 * k]), __uint_as_float(v[4 * k + 1]), __uint_as_float(v[4 * k + 2]),
                        __uint_as_float(v[4 * k + 3]));
 }
+__device__ __forceinline__ float4 word(const u32x8 &v, int k) {
+    return make_float4(__uint_as_float(v[4 * k]), __uint_as_float(v[4 * k + 1]), __uint_as_float(v[4 * k + 2]),
+                       __uint_as_float(v[4 * k + 3]));
+}
 
 // nquads is even (the list is padded with never-hit spheres) and four spare quads follow
-// it, so the read-ahead never leaves the array.  Two quads are requested while two are
-// tested.
-__device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, int nquads, const RayK &r, V3 o, V3 dh,
-                                            float tmin, int self_id, float &best_t, int &best_id) {
+// it, so the read-ahead never leaves the arrays.  Two quads are requested while two are
+// tested; a list of two quads is one request and one wait.
+__device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, const float4 *__restrict__ g2, int nquads,
+                                            const RayK &r, V3 o, V3 dh, float tmin, int self_id, float &best_t,
+                                            int &best_id) {
     u32x16 A0 = sload_quad<0>(g), A1 = sload_quad<64>(g);
+    u32x8 RA = sload_r2<0>(g2);
     __builtin_amdgcn_sched_barrier(0);
+    if (nquads <= 2) {
+        swait_quads(A0, A1, RA);
+        test_quad2(r, o, dh, word(A0, 0), word(A0, 1), word(A0, 2), word(A0, 3), word(RA, 0), word(A1, 0), word(A1, 1),
+                   word(A1, 2), word(A1, 3), word(RA, 1), tmin, 0, self_id, best_t, best_id);
+        nquads = 0; // skips the loop below
+    }
 #pragma unroll 1
     for (int q = 0; q < nquads; q += 4) {
-        swait_quads(A0, A1);
+        swait_quads(A0, A1, RA);
         u32x16 B0 = sload_quad<128>(g), B1 = sload_quad<192>(g);
+        u32x8 RB = sload_r2<32>(g2);
         __builtin_amdgcn_sched_barrier(0); // keep the requests ahead of the arithmetic they overlap with
-        test_quad(r, o, dh, word(A0, 0), word(A0, 1), word(A0, 2), word(A0, 3), tmin, 4 * q, self_id, best_t, best_id);
-        test_quad(r, o, dh, word(A1, 0), word(A1, 1), word(A1, 2), word(A1, 3), tmin, 4 * q + 4, self_id, best_t,
-                  best_id);
-        swait_quads(B0, B1);
+        test_quad2(r, o, dh, word(A0, 0), word(A0, 1), word(A0, 2), word(A0, 3), word(RA, 0), word(A1, 0), word(A1, 1),
+                   word(A1, 2), word(A1, 3), word(RA, 1), tmin, 4 * q, self_id, best_t, best_id);
+        swait_quads(B0, B1, RB);
         g += 16; // four quads
+        g2 += 4;
         A0 = sload_quad<0>(g);
         A1 = sload_quad<64>(g);
+        RA = sload_r2<0>(g2);
         __builtin_amdgcn_sched_barrier(0);
-        if (q + 2 < nquads) {
-            test_quad(r, o, dh, word(B0, 0), word(B0, 1), word(B0, 2), word(B0, 3), tmin, 4 * q + 8, self_id, best_t,
-                      best_id);
-            test_quad(r, o, dh, word(B1, 0), word(B1, 1), word(B1, 2), word(B1, 3), tmin, 4 * q + 12, self_id,
-                      best_t, best_id);
-        }
+        if (q + 2 < nquads)
+            test_quad2(r, o, dh, word(B0, 0), word(B0, 1), word(B0, 2), word(B0, 3), word(RB, 0), word(B1, 0),
+                       word(B1, 1), word(B1, 2), word(B1, 3), word(RB, 1), tmin, 4 * q + 8, self_id, best_t, best_id);
     }
-    swait_quads(A0, A1); // drain the read-ahead before the registers are reused
+    swait_quads(A0, A1, RA); // drain the read-ahead before the registers are reused
 }
 
 // Camera::genRay, src/Camera.cpp:124-135: jittered point on the 1x1 viewport.
@@ -189,34 +214,39 @@ struct Tile {
     int x0, y0;   // top-left pixel
     int vw, vh;   // valid width / height inside the image (<= 0: nothing to do)
     int row0;     // output row of y0
+    int wl, hl;   // log2 of the tile's width / height
 };
 
 __device__ __forceinline__ Tile decode_item(const KParams &p, unsigned item) {
     Tile t;
-    int strip_local = (int)(item / (unsigned)p.tiles_per_strip);
-    int rem = (int)(item - (unsigned)strip_local * (unsigned)p.tiles_per_strip);
-    int sub_row = rem / p.tiles_x;
-    int tile_x = rem - sub_row * p.tiles_x;
+    const int k = item >= (unsigned)p.n_items_big ? 1 : 0; // which shape
+    if (k) item -= (unsigned)p.n_items_big;
+    int strip_local = (int)(item / (unsigned)p.tiles_per_strip[k]);
+    int rem = (int)(item - (unsigned)strip_local * (unsigned)p.tiles_per_strip[k]);
+    int sub_row = rem / p.tiles_x[k];
+    int tile_x = rem - sub_row * p.tiles_x[k];
+    if (k) strip_local += p.n_strips_big;
     int strip = p.strip_first + strip_local * p.strip_stride;
-    t.x0 = tile_x << p.tile_w_log2;
-    int dy = sub_row << p.tile_h_log2;
+    t.wl = p.tile_w_log2[k];
+    t.hl = p.tile_h_log2[k];
+    t.x0 = tile_x << t.wl;
+    int dy = sub_row << t.hl;
     t.y0 = strip * RT_STRIP_ROWS + dy;
-    t.vw = min(1 << p.tile_w_log2, p.width - t.x0);
-    t.vh = min(1 << p.tile_h_log2, p.height - t.y0);
+    t.vw = min(1 << t.wl, p.width - t.x0);
+    t.vh = min(1 << t.hl, p.height - t.y0);
     t.row0 = p.strip_stride == 1 ? t.y0 : strip_local * RT_STRIP_ROWS + dy;
     return t;
 }
 
-// Persistent render kernel.  Work items are pixel tiles (all samples of 16, 64 or 256
-// pixels, chosen so that an item holds a few thousand samples); every wave pulls
-// items from one global counter until it runs dry, so the grid stays busy however
-// uneven the image is.  Inside an item the wave runs the path loop described at the
+// Persistent render kernel.  Work items are pixel tiles (all samples of 4 to 256 pixels,
+// chosen so that an item holds a few thousand samples, and a quarter of that for the
+// tiles at the end of the queue, so that the last items to finish are short); every
+// wave pulls items from one global counter until it runs dry, so the grid stays busy
+// however uneven the image is.  Inside an item the wave runs the path loop described at the
 // top of this file.
 template <int SRC, bool FULL>
-#ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 1
-#endif
-__global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParams p, DeviceScene sc, uchar4 *__restrict__ rgba,
+// the sphere-only variants are held to the register budget of five waves per SIMD
+__global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParams p, DeviceScene sc, uchar4 *__restrict__ rgba,
                                                             float4 *__restrict__ accum,
                                                             unsigned long long *__restrict__ rays_out,
                                                             unsigned *__restrict__ queue) {
@@ -224,6 +254,8 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
     // [0, 12 KiB): per-wave accumulators, 4 waves x 3 channels x 256 pixels; then the sphere words.
     float *acc_all = reinterpret_cast<float *>(smem);
     float4 *lds_sph = reinterpret_cast<float4 *>(smem + ACC_BYTES);
+    // the squared radii follow the pair words of the resident list / of one streamed tile
+    float4 *lds_r2 = lds_sph + 4 * (SRC == SRC_LDS_STREAMED ? STREAM_QUADS : p.n_quads);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -232,9 +264,16 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
     const int nquads = p.n_quads; // groups of four spheres, padding included
     if (SRC == SRC_LDS_RESIDENT) {
         for (int i = threadIdx.x; i < 4 * nquads; i += WG_THREADS) lds_sph[i] = sc.pairs[i];
+        for (int i = threadIdx.x; i < nquads; i += WG_THREADS) lds_r2[i] = sc.r2q[i];
     }
     __syncthreads();
 
+#ifdef RT_STATS
+    const unsigned long long t_start = wall_clock64();
+    unsigned long long t_fetch = t_start;
+    unsigned cur_item = 0;
+    int items_done = 0;
+#endif
     Path pt;
     pt.pix = -1;
     pt.o = pt.d = pt.dh = pt.T = pt.L = mk(0, 0, 0);
@@ -255,11 +294,11 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
 
     // wave-uniform item state
     bool have_item = false, queue_empty = false;
-    Tile tile = {0, 0, 0, 0, 0};
+    Tile tile = {0, 0, 0, 0, 0, 0, 0};
     int nvalid = 0;
     int cur_q = 0, cur_smp = 0;         // next (pixel, sample) of the item's pool, pixels fastest
     float inv_nvalid = 0.f, inv_vw = 0.f; // reciprocals for the small index divisions below
-    const int tile_px = 1 << (p.tile_w_log2 + p.tile_h_log2);
+    int tile_px = 0;
 
     for (;;) {
         // ---- take the next tile from the queue ----
@@ -271,6 +310,11 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
                 queue_empty = true;
             } else {
                 tile = decode_item(p, it);
+                tile_px = 1 << (tile.wl + tile.hl);
+#ifdef RT_STATS
+                t_fetch = wall_clock64();
+                cur_item = it;
+#endif
                 nvalid = (tile.vw > 0 && tile.vh > 0) ? tile.vw * tile.vh : 0;
                 inv_nvalid = nvalid > 0 ? 1.0f / (float)nvalid : 0.f;
                 inv_vw = tile.vw > 0 ? 1.0f / (float)tile.vw : 0.f;
@@ -306,13 +350,15 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
                 int cnt = min(STREAM_QUADS, nquads - base);
                 __syncthreads();
                 for (int i = threadIdx.x; i < 4 * cnt; i += WG_THREADS) lds_sph[i] = sc.pairs[4 * base + i];
+                for (int i = threadIdx.x; i < cnt; i += WG_THREADS) lds_r2[i] = sc.r2q[base + i];
                 __syncthreads();
-                if (active) scan_lds(lds_sph, cnt, 4 * base, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
+                if (active)
+                    scan_lds(lds_sph, lds_r2, cnt, 4 * base, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
             }
         } else if (SRC == SRC_LDS_RESIDENT) {
-            if (active) scan_lds(lds_sph, nquads, 0, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
+            if (active) scan_lds(lds_sph, lds_r2, nquads, 0, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
         } else {
-            if (active) scan_scalar(sc.pairs, nquads, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
+            if (active) scan_scalar(sc.pairs, sc.r2q, nquads, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
         }
 
         // ---- shade (Camera::getRayColor, src/Camera.cpp:137-157) ----
@@ -440,7 +486,7 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
                     if (smp < p.spp) {
                         int ly = (int)(((float)q + 0.5f) * inv_vw);
                         int lx = q - ly * tile.vw;
-                        pt.pix = (ly << p.tile_w_log2) + lx;
+                        pt.pix = (ly << tile.wl) + lx;
                         px = tile.x0 + lx;
                         py = tile.y0 + ly;
                         pt.gpix = (uint32_t)(py * p.width + px);
@@ -506,7 +552,7 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
         if (have_item && cur_smp >= p.spp && !__ballot(pt.pix >= 0)) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             for (int q = lane; q < tile_px; q += 64) {
-                int lx = q & ((1 << p.tile_w_log2) - 1), ly = q >> p.tile_w_log2;
+                int lx = q & ((1 << tile.wl) - 1), ly = q >> tile.wl;
                 if (lx < tile.vw && ly < tile.vh) {
                     size_t o = (size_t)(tile.row0 + ly) * (size_t)p.width + (size_t)(tile.x0 + lx);
                     float r = acc[q], g = acc[MAX_TILE_PX + q], b = acc[2 * MAX_TILE_PX + q];
@@ -529,8 +575,28 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(KParam
             }
             have_item = false;
             need_work = false;
+#ifdef RT_STATS
+            items_done++;
+            if (lane == 0) {
+                // longest item: duration in the high half, item index in the low half
+                unsigned long long d = wall_clock64() - t_fetch;
+                atomicMax(&g_times[6], (d << 32) | cur_item);
+                if (cur_item >= (unsigned)p.n_items_big) atomicMax(&g_times[7], (d << 32) | cur_item);
+            }
+#endif
         }
     }
+#ifdef RT_STATS
+    if (lane == 0 && items_done > 0) {
+        const unsigned long long t_end = wall_clock64();
+        atomicMin(&g_times[0], t_start);
+        atomicMin(&g_times[1], t_end);
+        atomicMax(&g_times[2], t_end);
+        atomicAdd(&g_times[3], t_end - t_start);
+        atomicAdd(&g_times[4], 1ull);
+        atomicMax(&g_times[5], (unsigned long long)items_done);
+    }
+#endif
 
     if (rays_out) {
         // wave-level sum, one atomic per wave
@@ -762,7 +828,8 @@ __global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const
         if (expanded) expanded[i] = hit && r.expanded ? 1 : 0;
         return;
     }
-    __shared__ float4 lds_sph[4 * STREAM_QUADS];
+    __shared__ float4 lds_sph[5 * STREAM_QUADS];
+    float4 *lds_r2 = lds_sph + 4 * STREAM_QUADS;
     const int i = blockIdx.x * WG_THREADS + threadIdx.x;
     const bool live = i < n_rays;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
@@ -781,8 +848,9 @@ __global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const
         int cnt = min(STREAM_QUADS, nquads - base);
         __syncthreads();
         for (int k = threadIdx.x; k < 4 * cnt; k += WG_THREADS) lds_sph[k] = sc.pairs[4 * base + k];
+        for (int k = threadIdx.x; k < cnt; k += WG_THREADS) lds_r2[k] = sc.r2q[base + k];
         __syncthreads();
-        if (live) scan_lds(lds_sph, cnt, 4 * base, rk, o, dh, tmin * len, -1, best_t, best_id);
+        if (live) scan_lds(lds_sph, lds_r2, cnt, 4 * base, rk, o, dh, tmin * len, -1, best_t, best_id);
     }
     best_t *= inv_len;
     if (live && expanded) expanded[i] = 0;
@@ -912,12 +980,14 @@ struct rt_ctx {
     std::string err;
     float4 *d_sph = nullptr;
     float4 *d_pairs = nullptr;
+    float4 *d_r2q = nullptr;
     int n_quads = 0;
     bool scalar_source = true;
     unsigned *d_queue = nullptr; // work-item counter of the persistent render kernel (256 B, zeroed per launch)
     int n_cus = 256;
     int wgs_per_cu = 8;
-    int force_tile = -1; // tuning: 0 = 32x8, 1 = 8x8, 2 = 4x4 work-item tiles
+    int force_tile = -1; // tuning: 0 = 32x8, 1 = 8x8, 2 = 4x4, 3 = 2x2, 4 = 1x1 work-item tiles everywhere
+    int tail_pct = 25;   // share of the frame (its last strips) rendered with the next smaller tile shape
     uint32_t *d_mat_id = nullptr;
     DMat *d_mats = nullptr;
     DLight *d_lights = nullptr;
@@ -951,6 +1021,7 @@ int fail(rt_ctx *ctx, int code, const std::string &msg) {
 void free_scene(rt_ctx *ctx) {
     if (ctx->d_sph) (void)hipFree(ctx->d_sph);
     if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
+    if (ctx->d_r2q) (void)hipFree(ctx->d_r2q);
     if (ctx->d_mat_id) (void)hipFree(ctx->d_mat_id);
     if (ctx->d_mats) (void)hipFree(ctx->d_mats);
     if (ctx->d_prims) (void)hipFree(ctx->d_prims);
@@ -962,7 +1033,7 @@ void free_scene(rt_ctx *ctx) {
     ctx->d_verts = nullptr;
     ctx->d_others = ctx->d_halo = ctx->d_sph_gid = nullptr;
     ctx->n_prims = ctx->n_others = ctx->n_halo = 0;
-    ctx->d_sph = ctx->d_pairs = nullptr;
+    ctx->d_sph = ctx->d_pairs = ctx->d_r2q = nullptr;
     ctx->d_mat_id = nullptr;
     ctx->d_mats = nullptr;
     ctx->have_scene = false;
@@ -994,6 +1065,20 @@ int local_strips(const rt_params *p) {
 
 } // namespace
 
+#ifdef RT_STATS
+extern "C" __attribute__((visibility("default"))) int rt_debug_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(g_stats)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_times), sizeof(g_times)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z) != hipSuccess) return -1;
+        unsigned long long t[8] = {~0ull, ~0ull, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_times), t, sizeof t) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 RT_API int rt_version(void) { return 102; }
 
 RT_API void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint32_t out[4]) {
@@ -1020,7 +1105,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
         return RT_ERR_HIP;
     }
     // allow the render kernels their dynamic LDS budget
-    size_t lds_max = ACC_BYTES + (size_t)RESIDENT_MAX * sizeof(float4);
+    size_t lds_max = ACC_BYTES + (size_t)RESIDENT_MAX / 4 * 5 * sizeof(float4);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_RESIDENT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_STREAMED, false>),
@@ -1040,6 +1125,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
     // where the scan takes sphere data from: scalar loads (default, fastest measured) or LDS
     // broadcast reads ("lds": resident copy for small scenes, streamed tiles for large ones)
     if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (v >= 0 && v <= 4) ctx->force_tile = v; }
+    if (const char *t = getenv("RT_AMD_TAIL_PCT")) { int v = atoi(t); if (v >= 0 && v <= 100) ctx->tail_pct = v; }
     const char *src = getenv("RT_AMD_SPHERE_SOURCE");
     ctx->scalar_source = !(src && strcmp(src, "lds") == 0);
     *out = ctx;
@@ -1063,6 +1149,7 @@ DeviceScene device_scene(const rt_ctx *ctx) {
     DeviceScene sc;
     sc.sph = ctx->d_sph;
     sc.pairs = ctx->d_pairs;
+    sc.r2q = ctx->d_r2q;
     sc.mat_id = ctx->d_mat_id;
     sc.mats = ctx->d_mats;
     sc.lights = ctx->d_lights;
@@ -1135,20 +1222,25 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
     }
     const int n_spheres = (int)sph.size();
     // pair-interleaved scan words: padded to a multiple of eight spheres with spheres that cannot
-    // be hit (r^2 = -1 makes the discriminant negative for every ray), plus four spare quads so
-    // that the scan's read-ahead never leaves the array
+    // pass the filter (q = -1e30), plus four spare quads so that the scan's read-ahead never leaves
+    // the arrays.  q = r^2 - |C|^2 is formed in double and enlarged by the filter's margin.
     const int n_quads = ((n_spheres + 7) / 8) * 2;
     const size_t n_slots = (size_t)(n_quads + 4) * 4;
     std::vector<float4> pairs(n_slots, make_float4(0, 0, 0, 0)); // n_slots spheres -> n_slots/2 pairs -> n_slots words
+    std::vector<float4> r2q(n_slots / 4, make_float4(0, 0, 0, 0));
     for (size_t i = 0; i < n_slots; ++i) {
-        float x = 0, y = 0, z = 0, r2 = -1.0f;
+        float x = 0, y = 0, z = 0, q = -1e30f, r2 = 0;
         if ((int)i < n_spheres) {
             const float4 &sp = sph[i];
-            x = sp.x; y = sp.y; z = sp.z; r2 = sp.w * sp.w;
+            x = sp.x; y = sp.y; z = sp.z;
+            r2 = sp.w * sp.w;
+            const double c2 = (double)x * x + (double)y * y + (double)z * z, rr = (double)sp.w * sp.w;
+            q = std::nextafter((float)(rr - c2 + (double)FILTER_MARGIN * (c2 + rr)), INFINITY);
         }
         float4 &A = pairs[(i / 2) * 2], &B = pairs[(i / 2) * 2 + 1];
-        if (i % 2 == 0) { A.x = x; A.z = y; B.x = z; B.z = r2; }
-        else { A.y = x; A.w = y; B.y = z; B.w = r2; }
+        if (i % 2 == 0) { A.x = x; A.z = y; B.x = z; B.z = q; }
+        else { A.y = x; A.w = y; B.y = z; B.w = q; }
+        reinterpret_cast<float *>(&r2q[i / 4])[i % 4] = r2;
     }
     std::vector<DMat> mats((size_t)n_mats);
     for (int i = 0; i < n_mats; ++i) {
@@ -1171,6 +1263,7 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
     int rc;
     if ((rc = to_device(ctx, &ctx->d_sph, sph)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_pairs, pairs)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, &ctx->d_r2q, r2q)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_mat_id, mid)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_mats, mats)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_prims, prims)) != RT_OK) return rc;
@@ -1263,30 +1356,50 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     k.flags = p->flags;
     k.strip_first = p->strip_first;
     k.strip_stride = p->strip_stride;
-    // work-item tile: a few thousand samples per item keep a wave's pool much longer than its
-    // longest path; small frames get smaller tiles so that the queue still holds several
-    // items per resident wave
+    // Work-item tiles: a few thousand samples per item keep a wave's pool much longer than its
+    // longest path; small frames get smaller tiles so that the queue still holds several items per
+    // resident wave.  The strips of the last part of the image (the end of the queue) use the next
+    // smaller shape: the kernel ends when the last item does, and short last items make a short
+    // tail.  Shapes depend on the whole frame only, never on the strip partition: the order in
+    // which a pixel's samples are summed follows from its tile, and any partition must produce
+    // the same bytes.
     int nstrips = local_strips(p);
     if (nstrips == 0) return RT_OK;
+    const int total_strips = (p->height + RT_STRIP_ROWS - 1) / RT_STRIP_ROWS;
+    int small_from = total_strips; // first global strip of the second shape
     {
         static const int shapes[5][2] = {{5, 3}, {3, 3}, {2, 2}, {1, 1}, {0, 0}}; // 32x8, 8x8, 4x4, 2x2, 1x1 (log2)
         const int spp = p->samples_per_pixel;
         int pick = spp >= 256 ? 2 : (spp >= 64 ? 1 : 0);
         auto items_of = [&](int i) {
             long long tx = (p->width + (1 << shapes[i][0]) - 1) >> shapes[i][0];
-            return (long long)nstrips * tx * (RT_STRIP_ROWS >> shapes[i][1]);
+            return (long long)total_strips * tx * (RT_STRIP_ROWS >> shapes[i][1]);
         };
+        auto samples_of = [&](int i) { return (long long)spp << (shapes[i][0] + shapes[i][1]); };
         const long long enough = 4LL * ctx->n_cus * 20;
-        while (pick < 2 && items_of(pick) < enough &&
-               (long long)spp << (shapes[pick + 1][0] + shapes[pick + 1][1]) >= 256)
-            ++pick;
-        if (ctx->force_tile >= 0) pick = ctx->force_tile;
-        k.tile_w_log2 = shapes[pick][0];
-        k.tile_h_log2 = shapes[pick][1];
+        while (pick < 2 && items_of(pick) < enough && samples_of(pick + 1) >= 256) ++pick;
+        int small = pick;
+        if (ctx->tail_pct > 0 && pick < 4 && samples_of(pick + 1) >= 1024) {
+            small = pick + 1;
+            small_from = total_strips - (int)(((long long)total_strips * ctx->tail_pct + 99) / 100);
+        }
+        if (ctx->force_tile >= 0) {
+            pick = small = ctx->force_tile;
+            small_from = total_strips;
+        }
+        k.tile_w_log2[0] = shapes[pick][0];
+        k.tile_h_log2[0] = shapes[pick][1];
+        k.tile_w_log2[1] = shapes[small][0];
+        k.tile_h_log2[1] = shapes[small][1];
     }
-    const int tw = 1 << k.tile_w_log2, th = 1 << k.tile_h_log2;
-    k.tiles_x = (p->width + tw - 1) / tw;
-    k.tiles_per_strip = k.tiles_x * (RT_STRIP_ROWS / th);
+    for (int i = 0; i < 2; ++i) {
+        const int tw = 1 << k.tile_w_log2[i], th = 1 << k.tile_h_log2[i];
+        k.tiles_x[i] = (p->width + tw - 1) / tw;
+        k.tiles_per_strip[i] = k.tiles_x[i] * (RT_STRIP_ROWS / th);
+    }
+    // local strips whose global index strip_first + j * strip_stride lies before small_from
+    long long big = small_from > p->strip_first ? ((long long)small_from - p->strip_first + p->strip_stride - 1) / p->strip_stride : 0;
+    k.n_strips_big = (int)(big < nstrips ? big : nstrips);
     k.n_quads = ctx->n_quads;
     k.n_lights = (p->flags & RT_FLAG_DIRECT_LIGHT) ? ctx->n_lights : 0;
     k.inv_w = 1.0f / (float)p->width;
@@ -1296,8 +1409,10 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     memcpy(k.cam + 6, ctx->cam.right, 12);
     memcpy(k.cam + 9, ctx->cam.down, 12);
     DeviceScene sc = device_scene(ctx);
-    long long items = (long long)nstrips * k.tiles_per_strip;
+    const long long items_big = (long long)k.n_strips_big * k.tiles_per_strip[0];
+    const long long items = items_big + (long long)(nstrips - k.n_strips_big) * k.tiles_per_strip[1];
     if (items > 0x7fffffffLL) return fail(ctx, RT_ERR_INVALID, "too many tiles for one call");
+    k.n_items_big = (int)items_big;
     k.n_items = (int)items;
     // persistent grid: enough workgroups to fill every CU at the kernel's occupancy; the
     // item queue does the balancing, so more workgroups than that would only idle
@@ -1310,19 +1425,22 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     unsigned long long *o_rays = (unsigned long long *)d_rays;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 256, st));
     // the general kernel serves lights, the non-sphere primitives and the selection halo
-    const bool lights = k.n_lights > 0 || ctx->n_others > 0 || ctx->n_halo > 0;
+    const bool full = k.n_lights > 0 || ctx->n_others > 0 || ctx->n_halo > 0;
     size_t lds = ACC_BYTES;
     int src = SRC_SCALAR;
-    if (!ctx->scalar_source) {
+    // The scalar-load scan keeps loads in flight across compiler-scheduled code, which is only safe
+    // while none of their registers is spilled; the general kernel is too register-hungry for that
+    // and always takes the sphere words from LDS.
+    if (!ctx->scalar_source || full) {
         const bool resident = ctx->n_quads * 4 <= RESIDENT_MAX;
         src = resident ? SRC_LDS_RESIDENT : SRC_LDS_STREAMED;
-        lds += (size_t)(resident ? (ctx->n_quads > 0 ? ctx->n_quads : 1) : STREAM_QUADS) * 4 * sizeof(float4);
+        lds += (size_t)(resident ? (ctx->n_quads > 0 ? ctx->n_quads : 1) : STREAM_QUADS) * 5 * sizeof(float4);
     }
 #define RT_LAUNCH(S, L)                                                                                   \
     hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays, ctx->d_queue)
-    if (src == SRC_SCALAR) { if (lights) RT_LAUNCH(SRC_SCALAR, true); else RT_LAUNCH(SRC_SCALAR, false); }
-    else if (src == SRC_LDS_RESIDENT) { if (lights) RT_LAUNCH(SRC_LDS_RESIDENT, true); else RT_LAUNCH(SRC_LDS_RESIDENT, false); }
-    else { if (lights) RT_LAUNCH(SRC_LDS_STREAMED, true); else RT_LAUNCH(SRC_LDS_STREAMED, false); }
+    if (src == SRC_SCALAR) RT_LAUNCH(SRC_SCALAR, false);
+    else if (src == SRC_LDS_RESIDENT) { if (full) RT_LAUNCH(SRC_LDS_RESIDENT, true); else RT_LAUNCH(SRC_LDS_RESIDENT, false); }
+    else { if (full) RT_LAUNCH(SRC_LDS_STREAMED, true); else RT_LAUNCH(SRC_LDS_STREAMED, false); }
 #undef RT_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;

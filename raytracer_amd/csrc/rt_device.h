@@ -73,55 +73,99 @@ __device__ __forceinline__ V3 random_unit(float u0, float u1) {
 // roots are the reference's roots times |d|, so the interval (tmin, closest) is
 // scaled by |d| on entry and the winning root by 1/|d| on exit.
 //
-// Spheres are stored in PAIRS so that one packed-FP32 instruction (v_pk_add_f32 /
-// v_pk_mul_f32 / v_pk_fma_f32) serves two spheres:
-//   word 2j   = (x0, x1, y0, y1)      word 2j+1 = (z0, z1, r0^2, r1^2)
+// The scan itself is a FILTER.  With |dh| = 1 the discriminant is the squared radius
+// minus the squared distance from the centre to the ray's line,
+//   disc = r^2 - |C_perp - O_perp|^2          (x_perp = x - dh (x.dh))
+//        = (r^2 - |C|^2) + (C.dh)^2 + 2 C.O_perp - |O_perp|^2,
+// i.e. a per-sphere constant q, two dot products with per-ray vectors, and a per-ray
+// constant: seven fused multiply-adds per sphere and one comparison against |O_perp|^2.
+// The terms are of the size of |C|^2 and cancel, so this form is only trusted up to a
+// margin: q is stored enlarged by FILTER_MARGIN*(|C|^2 + r^2), the per-ray threshold is
+// lowered by FILTER_MARGIN*|O|^2 (about four times the worst rounding error of the
+// chain), and every sphere that passes is decided by resolve_hit(), which forms the
+// discriminant from O - C, where rounding errors enter linearly in the coordinates.
+//
+// Spheres are stored in PAIRS so that one packed-FP32 instruction (v_pk_mul_f32 /
+// v_pk_fma_f32) serves two spheres:
+//   word 2j   = (x0, x1, y0, y1)      word 2j+1 = (z0, z1, q0, q1)
+// and their squared radii, which only resolve_hit() reads, in a separate array of one
+// float4 per group of four spheres.
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// Ray operands of the scan, replicated into both halves of a register pair:
-// the unit direction dh and the moment m = O x dh of the ray's line.
+constexpr float FILTER_MARGIN = 1.9073486328125e-6f; // 2^-19
+
+// Ray operands of the scan, replicated into both halves of a register pair: the unit
+// direction dh, twice the part of the origin perpendicular to it, and the threshold.
 struct RayK {
-    f2 dx, dy, dz, mx, my, mz;
+    f2 dx, dy, dz, kx, ky, kz;
+    float thr;
 };
 
 __device__ __forceinline__ RayK make_rayk(V3 o, V3 dh) {
     RayK r;
-    float mx = fmaf(o.y, dh.z, -(o.z * dh.y));
-    float my = fmaf(o.z, dh.x, -(o.x * dh.z));
-    float mz = fmaf(o.x, dh.y, -(o.y * dh.x));
+    float od = dot(o, dh);
+    V3 op = madd(o, dh, -od); // O_perp
     r.dx = (f2){dh.x, dh.x}; r.dy = (f2){dh.y, dh.y}; r.dz = (f2){dh.z, dh.z};
-    r.mx = (f2){mx, mx}; r.my = (f2){my, my}; r.mz = (f2){mz, mz};
+    r.kx = (f2){2.0f * op.x, 2.0f * op.x}; r.ky = (f2){2.0f * op.y, 2.0f * op.y}; r.kz = (f2){2.0f * op.z, 2.0f * op.z};
+    r.thr = fmaf(-FILTER_MARGIN, dot(o, o), dot(op, op));
     return r;
 }
 
-// Discriminant of two spheres in 9 packed FMAs.  With |dh| = 1,
-//   disc = hb^2 - c = r^2 - |(O - C) x dh|^2,   (O - C) x dh = m - C x dh,
-// i.e. the squared radius minus the squared distance from the centre to the ray's
-// line.  Rounding errors enter linearly in the coordinates (never through a rounded
-// |O|^2 or |C|^2), and every instruction is a fused multiply-add.
-__device__ __forceinline__ f2 pair_disc(const RayK &r, float4 A, float4 B) {
-    f2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
-    f2 wx = __builtin_elementwise_fma(cz, r.dy, __builtin_elementwise_fma(-cy, r.dz, r.mx));
-    f2 wy = __builtin_elementwise_fma(cx, r.dz, __builtin_elementwise_fma(-cz, r.dx, r.my));
-    f2 wz = __builtin_elementwise_fma(cy, r.dx, __builtin_elementwise_fma(-cx, r.dy, r.mz));
-    return __builtin_elementwise_fma(-wx, wx, __builtin_elementwise_fma(-wy, wy, __builtin_elementwise_fma(-wz, wz, r2)));
+// Filter value of two spheres in 7 packed instructions; the sphere can only be hit if
+// the value reaches RayK::thr.  One chain, so that every instruction reads a single
+// scalar register pair (the sphere words arrive in SGPRs).
+__device__ __forceinline__ f2 pair_filter(const RayK &r, float4 A, float4 B) {
+    f2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, q = {B.z, B.w};
+    f2 b = __builtin_elementwise_fma(cz, r.dz, __builtin_elementwise_fma(cy, r.dy, cx * r.dx));
+    f2 t = __builtin_elementwise_fma(b, b, q);
+    return __builtin_elementwise_fma(cz, r.kz, __builtin_elementwise_fma(cy, r.ky, __builtin_elementwise_fma(cx, r.kx, t)));
 }
 
-// Root selection for one sphere whose discriminant is non-negative (the rare path):
-// the roots of SphereObject::hitDetail (inc/RTObjects.h:143-149) with
-// Interval::surrounds' open interval (inc/RTGeometry.h:79-81), nearer root first.
-// hb = oc.dh and c = |oc|^2 - r^2 are formed here from oc = O - C (c accumulated onto
-// -r^2 so that the cancellation happens inside the fused multiply-adds); the roots
+#ifdef RT_STATS
+// tuning build only: wave-level event counters
+__device__ unsigned long long g_stats[8];
+__device__ unsigned long long g_times[8]; // first start, first end, last end, sum of durations, waves, max items
+__device__ __forceinline__ void stat(int k) {
+    unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&g_stats[k], 1ull);
+}
+__device__ __forceinline__ void stat_lanes(int k) {
+    unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&g_stats[k], (unsigned long long)__popcll(m));
+}
+#ifdef RT_STATS_TIMES_ONLY
+#define RT_STAT(k)
+#define RT_STAT_LANES(k)
+#else
+#define RT_STAT(k) stat(k)
+#define RT_STAT_LANES(k) stat_lanes(k)
+#endif
+#else
+#define RT_STAT(k)
+#define RT_STAT_LANES(k)
+#endif
+
+// The decision for one sphere that passed the filter (the rare path): the roots of
+// SphereObject::hitDetail (inc/RTObjects.h:135-149) with Interval::surrounds' open
+// interval (inc/RTGeometry.h:79-81), nearer root first.
+// With oc = O - C: hb = oc.dh, the discriminant is r^2 - |oc - hb dh|^2 (accumulated
+// onto r^2 inside the fused multiply-adds) and c = |oc|^2 - r^2 likewise; the roots
 // -hb -+ sqrt(disc) are taken as q and c/q with |q| = |hb| + sqrt(disc), so the root
 // near the origin does not lose its digits to cancellation.
 // `self_id` names the sphere whose surface the ray starts on (-1: none): its constant
 // term is exactly zero in real arithmetic but rounding noise of size ulp(|oc|)*r in
 // floats, so it is skipped here and handled in closed form by self_hit().
-__device__ __forceinline__ void resolve_hit(V3 o, V3 dh, float cx, float cy, float cz, float r2, float disc,
+__device__ __forceinline__ void resolve_hit(V3 o, V3 dh, float cx, float cy, float cz, float r2, float f, float thr,
                                             float tmin, int idx, int self_id, float &best_t, int &best_id) {
-    if (disc >= 0.0f) {
+    if (f >= thr) {
+        RT_STAT(4);       // sphere bodies entered (per wave)
+        RT_STAT_LANES(5); // ... (per lane)
         float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
         float hb = fmaf(ocx, dh.x, fmaf(ocy, dh.y, ocz * dh.z));
+        float px = fmaf(-hb, dh.x, ocx), py = fmaf(-hb, dh.y, ocy), pz = fmaf(-hb, dh.z, ocz);
+        float disc = fmaf(-px, px, fmaf(-py, py, fmaf(-pz, pz, r2)));
+        // a negative discriminant needs no branch: its square root is NaN, and no comparison below
+        // holds for a NaN
         float c = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -r2)));
         float sq = __builtin_amdgcn_sqrtf(disc);
         float q = -(hb + __builtin_copysignf(sq, hb)); // |q| = |hb| + sq
@@ -131,23 +175,83 @@ __device__ __forceinline__ void resolve_hit(V3 o, V3 dh, float cx, float cy, flo
         // one if that does; a nearer root >= best_t rules the farther one out as well
         float cand = t_near > tmin ? t_near : t_far;
         if (cand > tmin && cand < best_t && idx != self_id) {
+            RT_STAT_LANES(6); // closest-hit updates (per lane)
             best_t = cand;
             best_id = idx;
         }
     }
 }
 
-// Four spheres (two pair-words each) against one ray.
+// Filter chains of four spheres (two pair-words each), written one step at a time so that two
+// groups can be interleaved: consecutive packed instructions that depend on each other cost a
+// wait state, and a wave that has a SIMD to itself needs independent work to fill the pipeline.
+struct QuadF {
+    f2 F0, F1;
+};
+#define RT_QUAD_STEP(Q, OP0, OP1) Q.F0 = OP0; Q.F1 = OP1
+
+// The rare path of a group: decide every sphere that passed the filter.
+__device__ __forceinline__ void resolve_quad(const RayK &r, V3 o, V3 dh, float4 A0, float4 B0, float4 A1, float4 B1,
+                                             float4 R, const QuadF &q, float tmin, int idx, int self_id, float &best_t,
+                                             int &best_id) {
+    float m = fmaxf(fmaxf(q.F0.x, q.F0.y), fmaxf(q.F1.x, q.F1.y));
+    RT_STAT(0);       // quads scanned (per wave)
+    RT_STAT_LANES(1); // quads scanned (per lane)
+    if (m >= r.thr) {
+        RT_STAT(2);       // quad bodies entered (per wave)
+        RT_STAT_LANES(3); // ... (per lane)
+        resolve_hit(o, dh, A0.x, A0.z, B0.x, R.x, q.F0.x, r.thr, tmin, idx, self_id, best_t, best_id);
+        resolve_hit(o, dh, A0.y, A0.w, B0.y, R.y, q.F0.y, r.thr, tmin, idx + 1, self_id, best_t, best_id);
+        resolve_hit(o, dh, A1.x, A1.z, B1.x, R.z, q.F1.x, r.thr, tmin, idx + 2, self_id, best_t, best_id);
+        resolve_hit(o, dh, A1.y, A1.w, B1.y, R.w, q.F1.y, r.thr, tmin, idx + 3, self_id, best_t, best_id);
+    }
+}
+
+// Four spheres (two pair-words each, and their squared radii R) against one ray.
 __device__ __forceinline__ void test_quad(const RayK &r, V3 o, V3 dh, float4 A0, float4 B0, float4 A1, float4 B1,
-                                          float tmin, int idx, int self_id, float &best_t, int &best_id) {
-    f2 D0 = pair_disc(r, A0, B0);
-    f2 D1 = pair_disc(r, A1, B1);
-    float m = fmaxf(fmaxf(D0.x, D0.y), fmaxf(D1.x, D1.y));
-    if (m >= 0.0f) {
-        resolve_hit(o, dh, A0.x, A0.z, B0.x, B0.z, D0.x, tmin, idx, self_id, best_t, best_id);
-        resolve_hit(o, dh, A0.y, A0.w, B0.y, B0.w, D0.y, tmin, idx + 1, self_id, best_t, best_id);
-        resolve_hit(o, dh, A1.x, A1.z, B1.x, B1.z, D1.x, tmin, idx + 2, self_id, best_t, best_id);
-        resolve_hit(o, dh, A1.y, A1.w, B1.y, B1.w, D1.y, tmin, idx + 3, self_id, best_t, best_id);
+                                          float4 R, float tmin, int idx, int self_id, float &best_t, int &best_id) {
+    f2 x0 = {A0.x, A0.y}, y0 = {A0.z, A0.w}, z0 = {B0.x, B0.y}, q0 = {B0.z, B0.w};
+    f2 x1 = {A1.x, A1.y}, y1 = {A1.z, A1.w}, z1 = {B1.x, B1.y}, q1 = {B1.z, B1.w};
+    QuadF q;
+    RT_QUAD_STEP(q, x0 * r.dx, x1 * r.dx);
+    RT_QUAD_STEP(q, __builtin_elementwise_fma(y0, r.dy, q.F0), __builtin_elementwise_fma(y1, r.dy, q.F1));
+    RT_QUAD_STEP(q, __builtin_elementwise_fma(z0, r.dz, q.F0), __builtin_elementwise_fma(z1, r.dz, q.F1));
+    RT_QUAD_STEP(q, __builtin_elementwise_fma(q.F0, q.F0, q0), __builtin_elementwise_fma(q.F1, q.F1, q1));
+    RT_QUAD_STEP(q, __builtin_elementwise_fma(x0, r.kx, q.F0), __builtin_elementwise_fma(x1, r.kx, q.F1));
+    RT_QUAD_STEP(q, __builtin_elementwise_fma(y0, r.ky, q.F0), __builtin_elementwise_fma(y1, r.ky, q.F1));
+    RT_QUAD_STEP(q, __builtin_elementwise_fma(z0, r.kz, q.F0), __builtin_elementwise_fma(z1, r.kz, q.F1));
+    resolve_quad(r, o, dh, A0, B0, A1, B1, R, q, tmin, idx, self_id, best_t, best_id);
+}
+
+// Two groups of four spheres at once: the same arithmetic as two test_quad calls, with the
+// chains of the two groups interleaved (dependent instructions four apart).
+__device__ __forceinline__ void test_quad2(const RayK &r, V3 o, V3 dh, float4 A0, float4 B0, float4 A1, float4 B1,
+                                           float4 Ra, float4 C0, float4 D0, float4 C1, float4 D1, float4 Rb, float tmin,
+                                           int idx, int self_id, float &best_t, int &best_id) {
+    f2 x0 = {A0.x, A0.y}, y0 = {A0.z, A0.w}, z0 = {B0.x, B0.y}, q0 = {B0.z, B0.w};
+    f2 x1 = {A1.x, A1.y}, y1 = {A1.z, A1.w}, z1 = {B1.x, B1.y}, q1 = {B1.z, B1.w};
+    f2 x2 = {C0.x, C0.y}, y2 = {C0.z, C0.w}, z2 = {D0.x, D0.y}, q2 = {D0.z, D0.w};
+    f2 x3 = {C1.x, C1.y}, y3 = {C1.z, C1.w}, z3 = {D1.x, D1.y}, q3 = {D1.z, D1.w};
+    QuadF a, b;
+    RT_QUAD_STEP(a, x0 * r.dx, x1 * r.dx);
+    RT_QUAD_STEP(b, x2 * r.dx, x3 * r.dx);
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(y0, r.dy, a.F0), __builtin_elementwise_fma(y1, r.dy, a.F1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(y2, r.dy, b.F0), __builtin_elementwise_fma(y3, r.dy, b.F1));
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(z0, r.dz, a.F0), __builtin_elementwise_fma(z1, r.dz, a.F1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(z2, r.dz, b.F0), __builtin_elementwise_fma(z3, r.dz, b.F1));
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(a.F0, a.F0, q0), __builtin_elementwise_fma(a.F1, a.F1, q1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(b.F0, b.F0, q2), __builtin_elementwise_fma(b.F1, b.F1, q3));
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(x0, r.kx, a.F0), __builtin_elementwise_fma(x1, r.kx, a.F1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(x2, r.kx, b.F0), __builtin_elementwise_fma(x3, r.kx, b.F1));
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(y0, r.ky, a.F0), __builtin_elementwise_fma(y1, r.ky, a.F1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(y2, r.ky, b.F0), __builtin_elementwise_fma(y3, r.ky, b.F1));
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(z0, r.kz, a.F0), __builtin_elementwise_fma(z1, r.kz, a.F1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(z2, r.kz, b.F0), __builtin_elementwise_fma(z3, r.kz, b.F1));
+    // one test for both groups first: it keeps the two chains together ahead of the branch
+    float m = fmaxf(fmaxf(fmaxf(a.F0.x, a.F0.y), fmaxf(a.F1.x, a.F1.y)), fmaxf(fmaxf(b.F0.x, b.F0.y), fmaxf(b.F1.x, b.F1.y)));
+    if (m >= r.thr) {
+        resolve_quad(r, o, dh, A0, B0, A1, B1, Ra, a, tmin, idx, self_id, best_t, best_id);
+        resolve_quad(r, o, dh, C0, D0, C1, D1, Rb, b, tmin, idx + 4, self_id, best_t, best_id);
     }
 }
 

@@ -1,19 +1,26 @@
-import sys, ctypes as C, numpy as np
-sys.path.insert(0,'.')
-import raytracer_amd.api as api
-api.LIB_PATH='tools/librt_dbg.so'
+"""Tuning aid: event counters of a -DRT_STATS build (tools/v_stats.so) for one render of a scene."""
+import ctypes as C, os, sys
+sys.path.insert(0, '.')
+os.environ["RT_AMD_LIB"] = os.path.abspath(os.environ.get("STATS_LIB", "tools/v_stats.so"))
 from raytracer_amd import Renderer, RenderParams, scenes
-r=Renderer(0); s=scenes.random_spheres_scene(); r.set_scene(s)
-lib=api.load_library()
-out=(C.c_ulonglong*8)()
-lib.rt_debug_read(out)
-W,H,SPP=int(sys.argv[1]),int(sys.argv[2]),int(sys.argv[3])
-p=RenderParams(W,H,samples_per_pixel=SPP,max_depth=50)
-rgba,acc,rays=r.render_host(p)
-lib.rt_debug_read(out)
-o=list(out)
-nq=((s.n_spheres+7)//8)*2
-print('rays',rays,'ideal wave-scans',rays/64,'quads/scan',nq)
-print('loop iterations',o[4],' with any active lane',o[6],' active lanes per scanning iteration',o[5]/max(o[6],1))
-print('quad-branch entries',o[0],'per scan',o[0]/max(o[6],1),' avg lanes',o[1]/max(o[0],1))
-print('resolve entries (wave-level)',o[2],'per scan',o[2]/max(o[6],1),' avg lanes',o[3]/max(o[2],1))
+from raytracer_amd.api import load_library
+name = sys.argv[1] if len(sys.argv) > 1 else "random_spheres"
+W, H, spp, depth = (int(x) for x in (sys.argv[2:6] if len(sys.argv) > 5 else (600, 338, 32, 50)))
+lib = load_library()
+out = (C.c_ulonglong * 16)()
+r = Renderer(0); r.set_scene(scenes.by_name(name))
+lib.rt_debug_stats(out, 1)
+_, _, rays = r.render_host(RenderParams(W, H, spp, depth))
+lib.rt_debug_stats(out, 0)
+q_w, q_l, b_w, b_l, s_w, s_l, upd = list(out)[:7]
+print(f"{name}: rays {rays}, wave-quads {q_w}, lane-quads {q_l} (lanes/wave {q_l/max(q_w,1):.1f})")
+print(f"  quad bodies: per wave {b_w} = {100*b_w/max(q_w,1):.1f}% of quads; lanes inside {b_l/max(b_w,1):.2f}")
+print(f"  sphere bodies: per wave {s_w} = {s_w/max(b_w,1):.2f} per quad body; lanes inside {s_l/max(s_w,1):.2f}")
+print(f"  per ray: candidate spheres {s_l/max(rays,1):.2f}, closest-hit updates {upd/max(rays,1):.2f}")
+t0, e0, e1, tsum, nw, maxit = list(out)[8:14]
+tick = 1e-5  # wall_clock64 ticks at 100 MHz: 10 ns -> ms
+print(f"  waves with work {nw}: first finished after {(e0-t0)*tick:.2f} ms, last after {(e1-t0)*tick:.2f} ms, "
+      f"mean duration {tsum/max(nw,1)*tick:.2f} ms, most items on one wave {maxit}")
+longest, longest_small = list(out)[14:16]
+print(f"  longest item: {(longest >> 32)*tick:.2f} ms (item {longest & 0xffffffff}); longest small-tile item: "
+      f"{(longest_small >> 32)*tick:.2f} ms (item {longest_small & 0xffffffff})")
