@@ -35,10 +35,23 @@ namespace {
 
 constexpr int WG_THREADS = 256;
 constexpr int WAVES_PER_WG = 4;
-constexpr int MAX_TILE_PX = 256;             // largest pixel tile a work item may cover (32 x 8)
+constexpr int MAX_TILE_PX = 64;              // largest pixel tile a work item may cover (8 x 8)
 constexpr int RESIDENT_MAX = 4096;           // spheres kept resident in LDS (80 KiB)
 constexpr int STREAM_QUADS = 512;            // quads (4 spheres, 80 B) per streamed LDS tile (40 KiB)
-constexpr size_t ACC_BYTES = WAVES_PER_WG * MAX_TILE_PX * 3 * sizeof(float); // LDS accumulators
+constexpr int SLOT_WORDS = 3 * MAX_TILE_PX;  // one tile slot's accumulators: r, g, b planes of 64-bit sums
+constexpr int WAVE_LDS_WORDS = 2 * SLOT_WORDS + 8; // two slots and their tile descriptors
+constexpr size_t ACC_BYTES = WAVES_PER_WG * WAVE_LDS_WORDS * sizeof(unsigned long long); // per-wave LDS state
+
+// Radiance sums are kept in 32.32 fixed point: integer addition is exact, so a pixel's sum does
+// not depend on the order in which its samples finish -- which changes with the tile that
+// shares the wave, i.e. with timing -- and a frame renders to the same bytes every time and
+// under every strip partition.  One sample is clamped to [0, 2^30]; a NaN counts as 0.
+__device__ __forceinline__ unsigned long long to_fixed(float x) {
+    x = fminf(fmaxf(x, 0.0f), 1073741824.0f);
+    float hi = floorf(x);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)((x - hi) * 4294967296.0f);
+}
+__device__ __forceinline__ float from_fixed(unsigned long long v) { return (float)((double)v * (1.0 / 4294967296.0)); }
 constexpr float TMIN = 0.001f;               // CLOSEST_HIT_MIN_T, src/Camera.cpp:10
 
 static_assert(RT_STRIP_ROWS == 8, "tile shapes below assume 8-row strips");
@@ -48,14 +61,10 @@ struct KParams {
     int spp, max_depth, sample_offset;
     uint32_t seed, flags;
     int strip_first, strip_stride;
-    // work-item tiles come in two sizes: the strips above image row `small_from_strip * 8` use the
-    // first shape, the strips below it (the end of the queue) the second, smaller one
-    int tile_w_log2[2], tile_h_log2[2];
-    int tiles_x[2];         // tiles across the image
-    int tiles_per_strip[2]; // tiles_x * (8 / tile height)
-    int n_items_big;        // items of the first shape this call renders
-    int n_strips_big;       // local strips of the first shape
-    int n_items;            // items this call renders
+    int tile_w_log2, tile_h_log2; // work-item tile: 1x1 ... 32x8 pixels
+    int tiles_x;         // tiles across the image
+    int tiles_per_strip; // tiles_x * (8 / tile height)
+    int n_items;         // tiles this call renders
     int n_quads;     // sphere quads to scan (padding included)
     int n_lights;    // lights shaded at every hit (0 unless RT_FLAG_DIRECT_LIGHT)
     float inv_w, inv_h;
@@ -214,36 +223,31 @@ struct Tile {
     int x0, y0;   // top-left pixel
     int vw, vh;   // valid width / height inside the image (<= 0: nothing to do)
     int row0;     // output row of y0
-    int wl, hl;   // log2 of the tile's width / height
 };
 
 __device__ __forceinline__ Tile decode_item(const KParams &p, unsigned item) {
     Tile t;
-    const int k = item >= (unsigned)p.n_items_big ? 1 : 0; // which shape
-    if (k) item -= (unsigned)p.n_items_big;
-    int strip_local = (int)(item / (unsigned)p.tiles_per_strip[k]);
-    int rem = (int)(item - (unsigned)strip_local * (unsigned)p.tiles_per_strip[k]);
-    int sub_row = rem / p.tiles_x[k];
-    int tile_x = rem - sub_row * p.tiles_x[k];
-    if (k) strip_local += p.n_strips_big;
+    int strip_local = (int)(item / (unsigned)p.tiles_per_strip);
+    int rem = (int)(item - (unsigned)strip_local * (unsigned)p.tiles_per_strip);
+    int sub_row = rem / p.tiles_x;
+    int tile_x = rem - sub_row * p.tiles_x;
     int strip = p.strip_first + strip_local * p.strip_stride;
-    t.wl = p.tile_w_log2[k];
-    t.hl = p.tile_h_log2[k];
-    t.x0 = tile_x << t.wl;
-    int dy = sub_row << t.hl;
+    t.x0 = tile_x << p.tile_w_log2;
+    int dy = sub_row << p.tile_h_log2;
     t.y0 = strip * RT_STRIP_ROWS + dy;
-    t.vw = min(1 << t.wl, p.width - t.x0);
-    t.vh = min(1 << t.hl, p.height - t.y0);
+    t.vw = min(1 << p.tile_w_log2, p.width - t.x0);
+    t.vh = min(1 << p.tile_h_log2, p.height - t.y0);
     t.row0 = p.strip_stride == 1 ? t.y0 : strip_local * RT_STRIP_ROWS + dy;
     return t;
 }
 
-// Persistent render kernel.  Work items are pixel tiles (all samples of 4 to 256 pixels,
-// chosen so that an item holds a few thousand samples, and a quarter of that for the
-// tiles at the end of the queue, so that the last items to finish are short); every
-// wave pulls items from one global counter until it runs dry, so the grid stays busy
-// however uneven the image is.  Inside an item the wave runs the path loop described at the
-// top of this file.
+// Persistent render kernel.  Work items are pixel tiles (all samples of 1 to 256 pixels,
+// a couple of thousand samples each); every wave pulls items from one global counter until
+// it runs dry, so the grid stays busy however uneven the image is.  A wave holds up to TWO
+// tiles: when the pool of one runs dry, lanes that finish their paths start on the next
+// tile at once while the long paths of the old one run out, so small tiles cost no idle
+// lanes, and small tiles keep the longest item (the kernel cannot end before it does)
+// short.  Inside a tile the wave runs the path loop described at the top of this file.
 template <int SRC, bool FULL>
 // the sphere-only variants are held to the register budget of five waves per SIMD
 __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParams p, DeviceScene sc, uchar4 *__restrict__ rgba,
@@ -251,15 +255,17 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                                                             unsigned long long *__restrict__ rays_out,
                                                             unsigned *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [0, 12 KiB): per-wave accumulators, 4 waves x 3 channels x 256 pixels; then the sphere words.
-    float *acc_all = reinterpret_cast<float *>(smem);
+    // per-wave state first (two accumulator slots of 3 channels x 64 pixels and their tile
+    // descriptors), then the sphere words
+    unsigned long long *acc_all = reinterpret_cast<unsigned long long *>(smem);
     float4 *lds_sph = reinterpret_cast<float4 *>(smem + ACC_BYTES);
     // the squared radii follow the pair words of the resident list / of one streamed tile
     float4 *lds_r2 = lds_sph + 4 * (SRC == SRC_LDS_STREAMED ? STREAM_QUADS : p.n_quads);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float *acc = acc_all + wave * (3 * MAX_TILE_PX);
+    unsigned long long *acc = acc_all + wave * WAVE_LDS_WORDS;
+    int *desc = reinterpret_cast<int *>(acc + 2 * SLOT_WORDS); // slot s: desc[8 s ...] = x0, y0, vw, vh, row0
 
     const int nquads = p.n_quads; // groups of four spheres, padding included
     if (SRC == SRC_LDS_RESIDENT) {
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
 
 #ifdef RT_STATS
     const unsigned long long t_start = wall_clock64();
-    unsigned long long t_fetch = t_start;
-    unsigned cur_item = 0;
+    unsigned long long t_fetch[2] = {t_start, t_start};
+    unsigned long long cur_item[2] = {0, 0};
     int items_done = 0;
 #endif
     Path pt;
@@ -282,7 +288,6 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
     pt.depth = 0;
     pt.self_id = -1;
     unsigned long long my_rays = 0;
-    bool need_work = false;
     LightState ls;
     ls.light_i = -1;
     ls.hp = ls.hn = ls.nxt_o = ls.nxt_d = ls.att = mk(0, 0, 0);
@@ -292,47 +297,23 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
     ls.nxt_valid = false;
     const V3 cam_center = mk(p.cam[0], p.cam[1], p.cam[2]);
 
-    // wave-uniform item state
-    bool have_item = false, queue_empty = false;
-    Tile tile = {0, 0, 0, 0, 0, 0, 0};
+    // wave-uniform state: two tile slots.  At most one of them hands out samples (its pool is
+    // open); the other may still have paths in flight from before its pool ran dry.
+    bool queue_empty = false, pool_open = false;
+    bool have0 = false, have1 = false; // slot holds a tile whose result is not stored yet
+    int fill = 0;                      // the slot whose pool is open
+    Tile tile = {0, 0, 0, 0, 0};       // its tile
     int nvalid = 0;
-    int cur_q = 0, cur_smp = 0;         // next (pixel, sample) of the item's pool, pixels fastest
+    int cur_q = 0, cur_smp = 0;           // next (pixel, sample) of the open pool, pixels fastest
     float inv_nvalid = 0.f, inv_vw = 0.f; // reciprocals for the small index divisions below
-    int tile_px = 0;
+    const int tile_px = 1 << (p.tile_w_log2 + p.tile_h_log2);
 
     for (;;) {
-        // ---- take the next tile from the queue ----
-        if (!have_item && !queue_empty) {
-            unsigned it = 0;
-            if (lane == 0) it = atomicAdd(queue, 1u);
-            it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
-            if (it >= (unsigned)p.n_items) {
-                queue_empty = true;
-            } else {
-                tile = decode_item(p, it);
-                tile_px = 1 << (tile.wl + tile.hl);
-#ifdef RT_STATS
-                t_fetch = wall_clock64();
-                cur_item = it;
-#endif
-                nvalid = (tile.vw > 0 && tile.vh > 0) ? tile.vw * tile.vh : 0;
-                inv_nvalid = nvalid > 0 ? 1.0f / (float)nvalid : 0.f;
-                inv_vw = tile.vw > 0 ? 1.0f / (float)tile.vw : 0.f;
-                cur_q = 0;
-                cur_smp = nvalid > 0 ? 0 : p.spp; // an empty tile has an empty pool
-                for (int q = lane; q < tile_px; q += 64) {
-                    acc[q] = 0.f;
-                    acc[MAX_TILE_PX + q] = 0.f;
-                    acc[2 * MAX_TILE_PX + q] = 0.f;
-                }
-                have_item = true;
-                need_work = true;
-            }
-        }
+        const bool wave_live = have0 || have1 || !queue_empty;
         if (SRC == SRC_LDS_STREAMED) {
-            if (!__syncthreads_or(have_item)) break;
+            if (!__syncthreads_or(wave_live)) break;
         } else {
-            if (!have_item) break;
+            if (!wave_live) break;
         }
 
         const bool in_shadow = FULL && ls.light_i >= 0;
@@ -462,51 +443,122 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
             }
         }
         if (finished) {
-            atomicAdd(&acc[pt.pix], pt.L.x);
-            atomicAdd(&acc[MAX_TILE_PX + pt.pix], pt.L.y);
-            atomicAdd(&acc[2 * MAX_TILE_PX + pt.pix], pt.L.z);
+            atomicAdd(&acc[pt.pix], to_fixed(pt.L.x));
+            atomicAdd(&acc[MAX_TILE_PX + pt.pix], to_fixed(pt.L.y));
+            atomicAdd(&acc[2 * MAX_TILE_PX + pt.pix], to_fixed(pt.L.z));
             pt.pix = -1;
-            need_work = true;
         }
 
-        // ---- hand the next (pixel, sample) of the pool to every lane without a path:
-        //      ballot + prefix count, so the wave stays full until the pool is empty ----
+        // ---- a slot whose pool has run dry and whose last path has ended: tone-map and store
+        //      (convertRTColor, src/Camera.cpp:19-34) ----
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bool occupied = s ? have1 : have0;
+            if (!occupied || (pool_open && fill == s)) continue;
+            if (__ballot(pt.pix >= 0 && (pt.pix >= SLOT_WORDS) == (s == 1))) continue;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            const unsigned long long *a = acc + s * SLOT_WORDS;
+            const int *d = desc + 8 * s;
+            const int x0 = d[0], vw = d[2], vh = d[3], row0 = d[4];
+            for (int q = lane; q < tile_px; q += 64) {
+                int lx = q & ((1 << p.tile_w_log2) - 1), ly = q >> p.tile_w_log2;
+                if (lx < vw && ly < vh) {
+                    size_t o = (size_t)(row0 + ly) * (size_t)p.width + (size_t)(x0 + lx);
+                    float r = from_fixed(a[q]), g = from_fixed(a[MAX_TILE_PX + q]), b = from_fixed(a[2 * MAX_TILE_PX + q]);
+                    float cnt = (float)p.spp;
+                    if (accum) {
+                        if (p.flags & RT_FLAG_ACCUMULATE) {
+                            float4 prev = accum[o];
+                            r += prev.x; g += prev.y; b += prev.z; cnt += prev.w;
+                        }
+                        accum[o] = make_float4(r, g, b, cnt);
+                    }
+                    float inv = 1.0f / cnt;
+                    uchar4 px8;
+                    px8.x = (unsigned char)to_byte(r * inv);
+                    px8.y = (unsigned char)to_byte(g * inv);
+                    px8.z = (unsigned char)to_byte(b * inv);
+                    px8.w = 255;
+                    rgba[o] = px8;
+                }
+            }
+            if (s) have1 = false; else have0 = false;
+#ifdef RT_STATS
+            items_done++;
+            if (lane == 0) atomicMax(&g_times[6], ((wall_clock64() - t_fetch[s]) << 32) | cur_item[s]);
+#endif
+        }
+
+        // ---- hand the next (pixel, sample) of the open pool to every lane without a path
+        //      (ballot + prefix count); when the pool runs dry, open the next tile's in the free
+        //      slot and go on, so the wave stays full until the queue is empty ----
         bool fresh = false;
         int px = 0, py = 0;
-        {
-            unsigned long long m = __ballot(need_work);
-            if (m) {
+        for (unsigned long long m = __ballot(pt.pix < 0); m != 0; m = __ballot(pt.pix < 0)) {
+            if (!pool_open) {
+                if (queue_empty || (have0 && have1)) break;
+                unsigned it = 0;
+                if (lane == 0) it = atomicAdd(queue, 1u);
+                it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
+                if (it >= (unsigned)p.n_items) {
+                    queue_empty = true;
+                    break;
+                }
+                tile = decode_item(p, it);
+                nvalid = (tile.vw > 0 && tile.vh > 0) ? tile.vw * tile.vh : 0;
+                if (nvalid == 0) continue; // a tile outside the image: nothing to render or store
+                fill = have0 ? 1 : 0;
+                if (fill) have1 = true; else have0 = true;
+                pool_open = true;
+                inv_nvalid = 1.0f / (float)nvalid;
+                inv_vw = 1.0f / (float)tile.vw;
+                cur_q = 0;
+                cur_smp = 0;
+                unsigned long long *a = acc + fill * SLOT_WORDS;
+                for (int q = lane; q < tile_px; q += 64) {
+                    a[q] = 0ull;
+                    a[MAX_TILE_PX + q] = 0ull;
+                    a[2 * MAX_TILE_PX + q] = 0ull;
+                }
+                if (lane == 0) {
+                    int *d = desc + 8 * fill;
+                    d[0] = tile.x0; d[1] = tile.y0; d[2] = tile.vw; d[3] = tile.vh; d[4] = tile.row0;
+                }
+#ifdef RT_STATS
+                t_fetch[fill] = wall_clock64();
+                cur_item[fill] = it;
+#endif
+            }
+            const int asking = (int)__popcll(m);
+            if (pt.pix < 0) {
+                // idx < nvalid + 64 <= 128 and q < 64: the float reciprocals divide exactly
                 int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (need_work) {
-                    // idx < nvalid + 64 <= 320 and q < 256: the float reciprocals divide exactly
-                    int idx = cur_q + rank;
-                    int wraps = (int)(((float)idx + 0.5f) * inv_nvalid);
-                    int q = idx - wraps * nvalid;
-                    int smp = cur_smp + wraps;
-                    if (smp < p.spp) {
-                        int ly = (int)(((float)q + 0.5f) * inv_vw);
-                        int lx = q - ly * tile.vw;
-                        pt.pix = (ly << tile.wl) + lx;
-                        px = tile.x0 + lx;
-                        py = tile.y0 + ly;
-                        pt.gpix = (uint32_t)(py * p.width + px);
-                        pt.sample = (uint32_t)(smp + p.sample_offset);
-                        pt.call = 0;
-                        pt.T = mk(1, 1, 1);
-                        pt.L = mk(0, 0, 0);
-                        pt.depth = p.max_depth;
-                        pt.self_id = -1;
-                        fresh = true;
-                    }
-                    need_work = false;
+                int idx = cur_q + rank;
+                int wraps = (int)(((float)idx + 0.5f) * inv_nvalid);
+                int q = idx - wraps * nvalid;
+                int smp = cur_smp + wraps;
+                if (smp < p.spp) {
+                    int ly = (int)(((float)q + 0.5f) * inv_vw);
+                    int lx = q - ly * tile.vw;
+                    pt.pix = fill * SLOT_WORDS + (ly << p.tile_w_log2) + lx;
+                    px = tile.x0 + lx;
+                    py = tile.y0 + ly;
+                    pt.gpix = (uint32_t)(py * p.width + px);
+                    pt.sample = (uint32_t)(smp + p.sample_offset);
+                    pt.call = 0;
+                    pt.T = mk(1, 1, 1);
+                    pt.L = mk(0, 0, 0);
+                    pt.depth = p.max_depth;
+                    pt.self_id = -1;
+                    fresh = true;
                 }
-                if (cur_smp < p.spp) {
-                    cur_q += (int)__popcll(m);
-                    while (cur_q >= nvalid) {
-                        cur_q -= nvalid;
-                        ++cur_smp;
-                    }
-                }
+            }
+            {
+                int idx = cur_q + asking;
+                int wraps = (int)(((float)idx + 0.5f) * inv_nvalid);
+                cur_q = idx - wraps * nvalid;
+                cur_smp += wraps;
+                if (cur_smp >= p.spp) pool_open = false;
             }
         }
 
@@ -548,43 +600,6 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
             pt.self_id = ls.hself;
         }
 
-        // ---- tile done: tone-map and store (convertRTColor, src/Camera.cpp:19-34) ----
-        if (have_item && cur_smp >= p.spp && !__ballot(pt.pix >= 0)) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            for (int q = lane; q < tile_px; q += 64) {
-                int lx = q & ((1 << tile.wl) - 1), ly = q >> tile.wl;
-                if (lx < tile.vw && ly < tile.vh) {
-                    size_t o = (size_t)(tile.row0 + ly) * (size_t)p.width + (size_t)(tile.x0 + lx);
-                    float r = acc[q], g = acc[MAX_TILE_PX + q], b = acc[2 * MAX_TILE_PX + q];
-                    float cnt = (float)p.spp;
-                    if (accum) {
-                        if (p.flags & RT_FLAG_ACCUMULATE) {
-                            float4 prev = accum[o];
-                            r += prev.x; g += prev.y; b += prev.z; cnt += prev.w;
-                        }
-                        accum[o] = make_float4(r, g, b, cnt);
-                    }
-                    float inv = 1.0f / cnt;
-                    uchar4 px8;
-                    px8.x = (unsigned char)to_byte(r * inv);
-                    px8.y = (unsigned char)to_byte(g * inv);
-                    px8.z = (unsigned char)to_byte(b * inv);
-                    px8.w = 255;
-                    rgba[o] = px8;
-                }
-            }
-            have_item = false;
-            need_work = false;
-#ifdef RT_STATS
-            items_done++;
-            if (lane == 0) {
-                // longest item: duration in the high half, item index in the low half
-                unsigned long long d = wall_clock64() - t_fetch;
-                atomicMax(&g_times[6], (d << 32) | cur_item);
-                if (cur_item >= (unsigned)p.n_items_big) atomicMax(&g_times[7], (d << 32) | cur_item);
-            }
-#endif
-        }
     }
 #ifdef RT_STATS
     if (lane == 0 && items_done > 0) {
@@ -986,8 +1001,7 @@ struct rt_ctx {
     unsigned *d_queue = nullptr; // work-item counter of the persistent render kernel (256 B, zeroed per launch)
     int n_cus = 256;
     int wgs_per_cu = 8;
-    int force_tile = -1; // tuning: 0 = 32x8, 1 = 8x8, 2 = 4x4, 3 = 2x2, 4 = 1x1 work-item tiles everywhere
-    int tail_pct = 25;   // share of the frame (its last strips) rendered with the next smaller tile shape
+    int force_tile = -1; // tuning: 0 = 1x1, 1 = 2x2, 2 = 4x4, 3 = 8x8 work-item tiles
     uint32_t *d_mat_id = nullptr;
     DMat *d_mats = nullptr;
     DLight *d_lights = nullptr;
@@ -1124,8 +1138,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
     if (const char *w = getenv("RT_AMD_WGS_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 64) ctx->wgs_per_cu = v; }
     // where the scan takes sphere data from: scalar loads (default, fastest measured) or LDS
     // broadcast reads ("lds": resident copy for small scenes, streamed tiles for large ones)
-    if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (v >= 0 && v <= 4) ctx->force_tile = v; }
-    if (const char *t = getenv("RT_AMD_TAIL_PCT")) { int v = atoi(t); if (v >= 0 && v <= 100) ctx->tail_pct = v; }
+    if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (v >= 0 && v <= 3) ctx->force_tile = v; }
     const char *src = getenv("RT_AMD_SPHERE_SOURCE");
     ctx->scalar_source = !(src && strcmp(src, "lds") == 0);
     *out = ctx;
@@ -1356,50 +1369,27 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     k.flags = p->flags;
     k.strip_first = p->strip_first;
     k.strip_stride = p->strip_stride;
-    // Work-item tiles: a few thousand samples per item keep a wave's pool much longer than its
-    // longest path; small frames get smaller tiles so that the queue still holds several items per
-    // resident wave.  The strips of the last part of the image (the end of the queue) use the next
-    // smaller shape: the kernel ends when the last item does, and short last items make a short
-    // tail.  Shapes depend on the whole frame only, never on the strip partition: the order in
-    // which a pixel's samples are summed follows from its tile, and any partition must produce
-    // the same bytes.
+    // Work-item tiles: the smallest shape that still holds about five hundred samples.  Small items
+    // keep the longest one short (a tile whose every path runs to the depth limit costs 25 times
+    // the average, and the kernel cannot end before its last item does); much smaller ones would
+    // run dry before the long paths of the tile before them have ended, and a wave holds only
+    // two tiles (measured on 1200x675: 100 samples per item 3.5x slower, 400 to 1600 best).  The shape depends on the sample count only,
+    // never on the frame or the strip partition: the order in which a pixel's samples are summed
+    // follows from its tile, and any partition must produce the same bytes.
     int nstrips = local_strips(p);
     if (nstrips == 0) return RT_OK;
-    const int total_strips = (p->height + RT_STRIP_ROWS - 1) / RT_STRIP_ROWS;
-    int small_from = total_strips; // first global strip of the second shape
     {
-        static const int shapes[5][2] = {{5, 3}, {3, 3}, {2, 2}, {1, 1}, {0, 0}}; // 32x8, 8x8, 4x4, 2x2, 1x1 (log2)
+        static const int shapes[4][2] = {{0, 0}, {1, 1}, {2, 2}, {3, 3}}; // 1x1, 2x2, 4x4, 8x8 (log2)
         const int spp = p->samples_per_pixel;
-        int pick = spp >= 256 ? 2 : (spp >= 64 ? 1 : 0);
-        auto items_of = [&](int i) {
-            long long tx = (p->width + (1 << shapes[i][0]) - 1) >> shapes[i][0];
-            return (long long)total_strips * tx * (RT_STRIP_ROWS >> shapes[i][1]);
-        };
-        auto samples_of = [&](int i) { return (long long)spp << (shapes[i][0] + shapes[i][1]); };
-        const long long enough = 4LL * ctx->n_cus * 20;
-        while (pick < 2 && items_of(pick) < enough && samples_of(pick + 1) >= 256) ++pick;
-        int small = pick;
-        if (ctx->tail_pct > 0 && pick < 4 && samples_of(pick + 1) >= 1024) {
-            small = pick + 1;
-            small_from = total_strips - (int)(((long long)total_strips * ctx->tail_pct + 99) / 100);
-        }
-        if (ctx->force_tile >= 0) {
-            pick = small = ctx->force_tile;
-            small_from = total_strips;
-        }
-        k.tile_w_log2[0] = shapes[pick][0];
-        k.tile_h_log2[0] = shapes[pick][1];
-        k.tile_w_log2[1] = shapes[small][0];
-        k.tile_h_log2[1] = shapes[small][1];
+        int pick = 0;
+        while (pick < 3 && ((long long)spp << (shapes[pick][0] + shapes[pick][1])) < 480) ++pick;
+        if (ctx->force_tile >= 0) pick = ctx->force_tile;
+        k.tile_w_log2 = shapes[pick][0];
+        k.tile_h_log2 = shapes[pick][1];
     }
-    for (int i = 0; i < 2; ++i) {
-        const int tw = 1 << k.tile_w_log2[i], th = 1 << k.tile_h_log2[i];
-        k.tiles_x[i] = (p->width + tw - 1) / tw;
-        k.tiles_per_strip[i] = k.tiles_x[i] * (RT_STRIP_ROWS / th);
-    }
-    // local strips whose global index strip_first + j * strip_stride lies before small_from
-    long long big = small_from > p->strip_first ? ((long long)small_from - p->strip_first + p->strip_stride - 1) / p->strip_stride : 0;
-    k.n_strips_big = (int)(big < nstrips ? big : nstrips);
+    const int tw = 1 << k.tile_w_log2, th = 1 << k.tile_h_log2;
+    k.tiles_x = (p->width + tw - 1) / tw;
+    k.tiles_per_strip = k.tiles_x * (RT_STRIP_ROWS / th);
     k.n_quads = ctx->n_quads;
     k.n_lights = (p->flags & RT_FLAG_DIRECT_LIGHT) ? ctx->n_lights : 0;
     k.inv_w = 1.0f / (float)p->width;
@@ -1409,10 +1399,8 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     memcpy(k.cam + 6, ctx->cam.right, 12);
     memcpy(k.cam + 9, ctx->cam.down, 12);
     DeviceScene sc = device_scene(ctx);
-    const long long items_big = (long long)k.n_strips_big * k.tiles_per_strip[0];
-    const long long items = items_big + (long long)(nstrips - k.n_strips_big) * k.tiles_per_strip[1];
+    const long long items = (long long)nstrips * k.tiles_per_strip;
     if (items > 0x7fffffffLL) return fail(ctx, RT_ERR_INVALID, "too many tiles for one call");
-    k.n_items_big = (int)items_big;
     k.n_items = (int)items;
     // persistent grid: enough workgroups to fill every CU at the kernel's occupancy; the
     // item queue does the balancing, so more workgroups than that would only idle
