@@ -64,6 +64,27 @@ def cpu_baseline(scene, cfg, seconds_target=15.0):
     }
 
 
+def committed_traffic(args, world):
+    """HBM bytes per launch of render_kernel for the default command, from the separate rocprofv3 --pmc
+    passes whose summary is committed under profiles/ (FETCH_SIZE and WRITE_SIZE cannot be read from
+    inside this process).  FETCH_SIZE is doubled as the gfx950 counter tallies 128-byte requests at 64;
+    both counters report KiB.  None for any other workload or GPU count."""
+    if args.workload != "c3" or args.spp or world != 1:
+        return None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    rounds = sorted(d for d in os.listdir(os.path.join(here, "profiles")) if d.startswith("r")) \
+        if os.path.isdir(os.path.join(here, "profiles")) else []
+    for r in reversed(rounds):
+        f = os.path.join(here, "profiles", r, "pmc_summary.json")
+        if os.path.exists(f):
+            try:
+                d = json.load(open(f))
+                return int((2 * d["fetch"]["FETCH_SIZE"] + d["write"]["WRITE_SIZE"]) * 1024), f"profiles/{r}/pmc_summary.json"
+            except (KeyError, ValueError):
+                return None, None
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +186,7 @@ def main():
         rays_per_launch = my_rays / args.steps
         flops = rays_per_launch * (FLOP_PER_TEST * n_s + FLOP_PER_RAY)
         achieved = flops / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = committed_traffic(args, world)
         out = {
             "metric": "Msamples/sec (px*spp, depth<=50)",
             "value": round(samples / dt / 1e6, 3),
@@ -190,7 +212,8 @@ def main():
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "render_kernel",
                 "kernel_ms": round(kern_ms, 3),
                 "flop_model": f"rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}), rays/launch={rays_per_launch:.0f}",

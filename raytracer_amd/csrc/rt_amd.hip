@@ -1,18 +1,16 @@
 // rt_amd.hip — HIP kernels (gfx950) and the C ABI declared in include/rt_amd.h.
 //
 // Render kernel layout
-//   * the image is cut into workgroup tiles of 32x8 pixels; a workgroup is four
-//     wavefronts, each owning one 8x8 pixel tile and the pool of
-//     (pixel, sample) work items of that tile;
-//   * a lane carries one path.  Every iteration all lanes of a wave scan the
-//     whole sphere list (brute force, spheres broadcast from LDS), then shade and
-//     bounce.  A lane whose path ended adds its radiance to the tile's fp32
-//     accumulator in LDS and takes the next work item of the pool; the new item
-//     indices come from a ballot + prefix count, so the wave stays full until
-//     the pool is empty;
-//   * when the pool is drained lane l tone-maps pixel l of the tile.
-// Scenes that fit the LDS budget are staged once; larger ones are streamed in
-// tiles shared by the whole workgroup.
+//   * the image is cut into 8-row strips (the unit of the multi-GPU partition) and the
+//     strips into small square tiles; a work item is all samples of one tile, and the
+//     waves of a persistent grid pull items from one global counter;
+//   * a lane carries one path.  Every iteration all lanes of a wave scan the whole
+//     sphere list (brute force; sphere words arrive through scalar loads, or from LDS in
+//     the general variant), then shade and bounce.  A lane whose path ended adds its
+//     radiance to its tile's fixed-point accumulator in LDS and takes the next
+//     (pixel, sample) of the open pool; indices come from a ballot + prefix count;
+//   * a wave holds two tiles, so lanes freed near the end of one start on the next at
+//     once; a tile whose pool is dry and whose last path has ended is tone-mapped and stored.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

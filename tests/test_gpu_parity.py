@@ -384,6 +384,26 @@ def test_sphere_source_knob_changes_no_byte(monkeypatch):
         assert imgs[0][2] == imgs[1][2]
 
 
+def test_tile_shape_knob_changes_no_byte(monkeypatch):
+    """Radiance sums are exact integers (32.32 fixed point), so the work-item tile shape -- which decides
+    the order in which a pixel's samples are added -- cannot change a byte; nor can the wave a tile lands on."""
+    from raytracer_amd import Renderer
+
+    scene = scenes.small_scene(bubble=True)
+    p = RenderParams(150, 83, 40, 12, seed=9)  # frame sizes that are no multiple of any tile
+    imgs = []
+    for tile in ("0", "1", "2", "3"):
+        monkeypatch.setenv("RT_AMD_TILE", tile)
+        r = Renderer(0)
+        r.set_scene(scene)
+        imgs.append(r.render_host(p, want_accum=True))
+        r.close()
+    for other in imgs[1:]:
+        assert np.array_equal(imgs[0][0], other[0])
+        assert np.array_equal(imgs[0][1], other[1])
+        assert imgs[0][2] == other[2]
+
+
 # --------------------------------------------------------------------------
 # BASELINE.json's full sizes, through size-independent properties
 # --------------------------------------------------------------------------
