@@ -40,17 +40,22 @@ constexpr int SLOT_WORDS = 3 * MAX_TILE_PX;  // one tile slot's accumulators: r,
 constexpr int WAVE_LDS_WORDS = 2 * SLOT_WORDS + 8; // two slots and their tile descriptors
 constexpr size_t ACC_BYTES = WAVES_PER_WG * WAVE_LDS_WORDS * sizeof(unsigned long long); // per-wave LDS state
 
-// Radiance sums are kept in 32.32 fixed point: integer addition is exact, so a pixel's sum does
-// not depend on the order in which its samples finish -- which changes with the tile that
+// Radiance sums are kept in signed 40.24 fixed point: integer addition is exact, so a pixel's sum
+// does not depend on the order in which its samples finish -- which changes with the tile that
 // shares the wave, i.e. with timing -- and a frame renders to the same bytes every time and
-// under every strip partition.  One sample is clamped to [0, 2^30]; a NaN counts as 0.
+// under every strip partition.  One sample is clamped to +-2^30 (a NaN counts as 0) and
+// resolved to 2^-24; the sum holds 2^39, i.e. 2^26 samples of average radiance 8192.
 __device__ __forceinline__ unsigned long long to_fixed(float x) {
-    x = fminf(fmaxf(x, 0.0f), 1073741824.0f);
-    float hi = floorf(x);
-    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)((x - hi) * 4294967296.0f);
+    float m = fminf(fmaxf(fabsf(x), 0.0f), 1073741824.0f);
+    float hi = floorf(m);
+    long long v = (long long)(((unsigned long long)(unsigned)hi << 24) | (unsigned long long)(unsigned)((m - hi) * 16777216.0f));
+    return (unsigned long long)(x < 0.0f ? -v : v);
 }
-__device__ __forceinline__ float from_fixed(unsigned long long v) { return (float)((double)v * (1.0 / 4294967296.0)); }
-constexpr float TMIN = 0.001f;               // CLOSEST_HIT_MIN_T, src/Camera.cpp:10
+__device__ __forceinline__ float from_fixed(unsigned long long v) {
+    return (float)((double)(long long)v * (1.0 / 16777216.0));
+}
+
+constexpr float TMIN = 0.001f; // CLOSEST_HIT_MIN_T, src/Camera.cpp:10
 
 static_assert(RT_STRIP_ROWS == 8, "tile shapes below assume 8-row strips");
 
@@ -59,7 +64,7 @@ struct KParams {
     int spp, max_depth, sample_offset;
     uint32_t seed, flags;
     int strip_first, strip_stride;
-    int tile_w_log2, tile_h_log2; // work-item tile: 1x1 ... 32x8 pixels
+    int tile_w_log2, tile_h_log2; // work-item tile: 1x1 ... 8x8 pixels
     int tiles_x;         // tiles across the image
     int tiles_per_strip; // tiles_x * (8 / tile height)
     int n_items;         // tiles this call renders
@@ -319,6 +324,15 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         // a path with no depth left (max_depth == 0) contributes black and ends at once
         bool finished = pt.pix >= 0 && pt.depth <= 0 && !in_shadow;
 
+#if defined(RT_STATS) && !defined(RT_STATS_TIMES_ONLY)
+        {
+            unsigned long long am = __ballot(active);
+            if (lane == 0) {
+                atomicAdd(&g_stats[0], 1ull);                            // scan iterations (per wave)
+                atomicAdd(&g_stats[1], (unsigned long long)__popcll(am)); // lanes with a ray in them
+            }
+        }
+#endif
         // ---- closest hit over all spheres (SceneManager::hitClosest, src/RayTracer.cpp:77-82) ----
         float best_t = __builtin_inff(); // in units of |d|
         int best_id = -1;

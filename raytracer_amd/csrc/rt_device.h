@@ -195,8 +195,6 @@ __device__ __forceinline__ void resolve_quad(const RayK &r, V3 o, V3 dh, float4 
                                              float4 R, const QuadF &q, float tmin, int idx, int self_id, float &best_t,
                                              int &best_id) {
     float m = fmaxf(fmaxf(q.F0.x, q.F0.y), fmaxf(q.F1.x, q.F1.y));
-    RT_STAT(0);       // quads scanned (per wave)
-    RT_STAT_LANES(1); // quads scanned (per lane)
     if (m >= r.thr) {
         RT_STAT(2);       // quad bodies entered (per wave)
         RT_STAT_LANES(3); // ... (per lane)

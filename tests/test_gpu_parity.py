@@ -385,7 +385,7 @@ def test_sphere_source_knob_changes_no_byte(monkeypatch):
 
 
 def test_tile_shape_knob_changes_no_byte(monkeypatch):
-    """Radiance sums are exact integers (32.32 fixed point), so the work-item tile shape -- which decides
+    """Radiance sums are exact integers (40.24 fixed point), so the work-item tile shape -- which decides
     the order in which a pixel's samples are added -- cannot change a byte; nor can the wave a tile lands on."""
     from raytracer_amd import Renderer
 
