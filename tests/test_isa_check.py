@@ -1,0 +1,50 @@
+"""The build's ISA check (tools/check_isa.py): inline-asm scalar loads that are still in flight must not
+be touched by compiler-scheduled code.  Synthetic assembly exercises the analysis; the real kernel is
+checked by __graft_entry__.build()."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "tools", "check_isa.py"))
+check_isa = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(check_isa)
+
+
+def kernel(body: str) -> str:
+    return "k1:                                    ; @k1\n" + body + "\n\ts_endpgm\n.end_amdhsa_kernel\n"
+
+
+LOAD = "\t;;#ASMSTART\n\ts_load_dwordx4 s[8:11], s[2:3], 0\n\t;;#ASMEND\n"
+WAIT = "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n"
+
+
+def test_use_after_wait_is_clean():
+    asm = kernel(LOAD + "\tv_mov_b32_e32 v0, s4\n" + WAIT + "\tv_mov_b32_e32 v1, s9\n")
+    assert check_isa.check(asm) == []
+
+
+def test_read_and_spill_before_wait_are_flagged():
+    asm = kernel(LOAD + "\tv_mov_b32_e32 v1, s9\n\tv_writelane_b32 v5, s10, 3\n" + WAIT)
+    problems = check_isa.check(asm)
+    assert len(problems) == 2 and "s[9]" in problems[0] and "s[10]" in problems[1]
+
+
+def test_compiler_waits_do_not_count():
+    asm = kernel(LOAD + "\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v1, s[8:9]\n" + WAIT)
+    assert len(check_isa.check(asm)) == 1
+
+
+def test_hazard_reached_through_a_branch():
+    # the wait sits on the fall-through path only; the taken branch reaches a use without it
+    asm = kernel(LOAD + "\ts_cbranch_scc1 .LBB0_2\n" + WAIT + ".LBB0_2:\n\tv_add_f32_e32 v0, s11, v0\n")
+    assert len(check_isa.check(asm)) == 1
+    # with the wait ahead of the branch both paths are clean
+    asm = kernel(LOAD + WAIT + "\ts_cbranch_scc1 .LBB0_2\n\tv_mov_b32_e32 v2, s8\n.LBB0_2:\n\tv_add_f32_e32 v0, s11, v0\n")
+    assert check_isa.check(asm) == []
+
+
+def test_loop_carried_load():
+    # a load issued at the bottom of a loop and waited for at its top: clean; touching it in between: flagged
+    loop = ".LBB0_1:\n" + WAIT + "\tv_mov_b32_e32 v0, s8\n" + LOAD + "{extra}\ts_cbranch_scc1 .LBB0_1\n" + WAIT
+    assert check_isa.check(kernel(LOAD + loop.format(extra=""))) == []
+    assert len(check_isa.check(kernel(LOAD + loop.format(extra="\ts_mov_b32 s20, s11\n")))) == 1
