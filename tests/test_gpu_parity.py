@@ -628,3 +628,29 @@ def test_gpu_primitive_and_halo_kats(renderer, refine):
         if not refine and "tie" in case["name"]:
             continue  # single precision may round the two equal distances apart
         check_prim_kat(case, first_hit, 1e-6 if refine else 1e-5)
+
+
+def test_filter_is_conservative_far_from_the_origin(renderer, oracle64):
+    """The scan's 7-instruction filter cancels terms of the size of |C|^2; its margins must keep it
+    conservative wherever the scene sits.  The random-spheres scene is moved far from the origin (small
+    spheres at coordinates ~3000 lose all but ~11 bits of their radius to single precision): the plain
+    scan may then disagree with the oracle on marginal rays, but never on a clear one, and the refined
+    path stays exact."""
+    base = scenes.random_spheres_scene()
+    shift = np.array([2000.0, -1500.0, 1000.0])
+    scene = scenes.Scene("shifted", base.spheres.copy(), base.mat_id, base.mats,
+                         scenes.make_camera(np.array([13.0, -3.0, 2.0]) + shift, (-13, 3, -2)))
+    for k, ax in enumerate(("cx", "cy", "cz")):
+        scene.spheres[ax] = (base.spheres[ax].astype(np.float64) + shift[k]).astype(np.float32)
+    renderer.set_scene(scene)
+    org, dirs = oracle64.primary_rays(scene.camera, 320, 180)
+    oid, ot, _, _, margin = oracle64.first_hit(scene, org, dirs, tmin=TMIN, want_margin=True)
+    ids, t, _, _ = renderer.first_hit(org, dirs, tmin=TMIN, refine=False)
+    bad = ids != oid
+    assert bad.mean() < 0.02
+    assert np.all(margin[bad] < 3e-2), f"clear rays disagree: margins {np.sort(margin[bad])[-5:]}"
+    rid, rt, _, _ = renderer.first_hit(org, dirs, tmin=TMIN, refine=True)
+    assert np.array_equal(rid, oid)
+    hit = oid >= 0
+    assert np.all(np.abs(rt[hit] - ot[hit]) <= 1e-5 * np.abs(ot[hit]))
+    assert (oid > 0).mean() > 0.2  # the small spheres are in view, not just the ground
