@@ -654,3 +654,37 @@ def test_filter_is_conservative_far_from_the_origin(renderer, oracle64):
     hit = oid >= 0
     assert np.all(np.abs(rt[hit] - ot[hit]) <= 1e-5 * np.abs(ot[hit]))
     assert (oid > 0).mean() > 0.2  # the small spheres are in view, not just the ground
+
+
+@pytest.mark.parametrize("W,H,spp,depth", [(37, 19, 1, 50), (64, 64, 2, 30), (130, 70, 3, 12), (9, 9, 130, 8),
+                                           (17, 33, 700, 6)])
+def test_work_distribution_never_changes_a_byte(monkeypatch, W, H, spp, depth):
+    """Tiny pools with long paths (both tile slots draining), partial tiles at the borders, every tile shape
+    and several strip partitions: image, sums and ray count always equal the plain single render."""
+    from raytracer_amd import Renderer
+
+    scene = scenes.small_scene(bubble=True)
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        base, base_acc, base_rays = r.render_host(RenderParams(W, H, spp, depth, seed=17), want_accum=True)
+    assert np.all(base_acc[:, :, 3] == spp) and np.all(base[:, :, 3] == 255)
+    for tile in ("0", "1", "2", "3"):
+        monkeypatch.setenv("RT_AMD_TILE", tile)
+        with Renderer(0) as r:
+            r.set_scene(scene)
+            for world in (1, 3):
+                img = np.zeros_like(base)
+                acc = np.zeros_like(base_acc)
+                total = 0
+                for rank in range(world):
+                    q = RenderParams(W, H, spp, depth, seed=17, strip_first=rank, strip_stride=world)
+                    part, part_acc, rays = r.render_host(q, want_accum=True)
+                    total += rays
+                    for k in range(output_rows(q) // 8 if world > 1 else 1):
+                        y0 = (rank + k * world) * 8 if world > 1 else 0
+                        h = min(8, H - y0) if world > 1 else H
+                        if h > 0:
+                            img[y0:y0 + h] = part[k * 8:k * 8 + h]
+                            acc[y0:y0 + h] = part_acc[k * 8:k * 8 + h]
+                assert np.array_equal(img, base) and np.array_equal(acc, base_acc), (tile, world)
+                assert total == base_rays
