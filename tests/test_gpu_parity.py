@@ -656,17 +656,22 @@ def test_filter_is_conservative_far_from_the_origin(renderer, oracle64):
     assert (oid > 0).mean() > 0.2  # the small spheres are in view, not just the ground
 
 
-@pytest.mark.parametrize("W,H,spp,depth", [(37, 19, 1, 50), (64, 64, 2, 30), (130, 70, 3, 12), (9, 9, 130, 8),
-                                           (17, 33, 700, 6)])
-def test_work_distribution_never_changes_a_byte(monkeypatch, W, H, spp, depth):
+@pytest.mark.parametrize("scene_name,W,H,spp,depth", [("small_bubble", 37, 19, 1, 50), ("small_bubble", 64, 64, 2, 30),
+                                                      ("small_bubble", 130, 70, 3, 12), ("small_bubble", 9, 9, 130, 8),
+                                                      ("small_bubble", 17, 33, 700, 6), ("mixed_lit", 45, 27, 2, 20),
+                                                      ("mixed_lit", 21, 13, 150, 6)])
+def test_work_distribution_never_changes_a_byte(monkeypatch, scene_name, W, H, spp, depth):
     """Tiny pools with long paths (both tile slots draining), partial tiles at the borders, every tile shape
-    and several strip partitions: image, sums and ray count always equal the plain single render."""
+    and several strip partitions, for the sphere-only and the general kernel: image, sums and ray count
+    always equal the plain single render."""
     from raytracer_amd import Renderer
+    from raytracer_amd.api import FLAG_DIRECT_LIGHT
 
-    scene = scenes.small_scene(bubble=True)
+    scene = scenes.by_name(scene_name)
+    flags = FLAG_DIRECT_LIGHT if scene_name == "mixed_lit" else 0
     with Renderer(0) as r:
         r.set_scene(scene)
-        base, base_acc, base_rays = r.render_host(RenderParams(W, H, spp, depth, seed=17), want_accum=True)
+        base, base_acc, base_rays = r.render_host(RenderParams(W, H, spp, depth, seed=17, flags=flags), want_accum=True)
     assert np.all(base_acc[:, :, 3] == spp) and np.all(base[:, :, 3] == 255)
     for tile in ("0", "1", "2", "3"):
         monkeypatch.setenv("RT_AMD_TILE", tile)
@@ -677,7 +682,7 @@ def test_work_distribution_never_changes_a_byte(monkeypatch, W, H, spp, depth):
                 acc = np.zeros_like(base_acc)
                 total = 0
                 for rank in range(world):
-                    q = RenderParams(W, H, spp, depth, seed=17, strip_first=rank, strip_stride=world)
+                    q = RenderParams(W, H, spp, depth, seed=17, flags=flags, strip_first=rank, strip_stride=world)
                     part, part_acc, rays = r.render_host(q, want_accum=True)
                     total += rays
                     for k in range(output_rows(q) // 8 if world > 1 else 1):
