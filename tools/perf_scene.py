@@ -6,10 +6,11 @@ from raytracer_amd import Renderer, RenderParams, scenes
 ap = argparse.ArgumentParser()
 ap.add_argument('--scene', default='grid10k'); ap.add_argument('--w', type=int, default=480); ap.add_argument('--h', type=int, default=270)
 ap.add_argument('--spp', type=int, default=16); ap.add_argument('--depth', type=int, default=50); ap.add_argument('--reps', type=int, default=3)
+ap.add_argument('--lights', action='store_true', help='render with RT_FLAG_DIRECT_LIGHT')
 a = ap.parse_args()
 sc = scenes.by_name(a.scene)
 r = Renderer(0); r.set_scene(sc)
-p = RenderParams(a.w, a.h, a.spp, a.depth)
+p = RenderParams(a.w, a.h, a.spp, a.depth, flags=2 if a.lights else 0)
 rgba = torch.zeros((a.h, a.w, 4), dtype=torch.uint8, device='cuda'); rays = torch.zeros(1, dtype=torch.int64, device='cuda')
 r.render_device(p, rgba, None, rays); torch.cuda.synchronize(); rays.zero_()
 t0 = time.perf_counter()
