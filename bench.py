@@ -5,7 +5,7 @@ A "step" is one full render of the frame through the C ABI (ray generation ->
 bounce loop -> tone-map; for N > 1 also the RCCL gather of the strips onto rank 0).
 The scene is already resident in HBM when the timed region starts.
 
-Workloads (BASELINE.json configs):
+Workloads (the benchmark configurations c2..c5):
   c3  random-spheres scene (485 spheres), 1200x675, 500 spp, depth 50   [default]
       with N GPUs the frame grows to 1200 x (675*N) so that every GPU keeps the
       same amount of work (weak scaling); strips of 8 rows are dealt round-robin.

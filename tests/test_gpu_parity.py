@@ -405,7 +405,7 @@ def test_tile_shape_knob_changes_no_byte(monkeypatch):
 
 
 # --------------------------------------------------------------------------
-# BASELINE.json's full sizes, through size-independent properties
+# the benchmark configurations at full size, through size-independent properties
 # --------------------------------------------------------------------------
 def _downsample(img, fy, fx):
     h, w = img.shape[0] // fy * fy, img.shape[1] // fx * fx
