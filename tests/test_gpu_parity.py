@@ -693,3 +693,23 @@ def test_work_distribution_never_changes_a_byte(monkeypatch, scene_name, W, H, s
                             acc[y0:y0 + h] = part_acc[k * 8:k * 8 + h]
                 assert np.array_equal(img, base) and np.array_equal(acc, base_acc), (tile, world)
                 assert total == base_rays
+
+
+def test_general_kernel_with_a_streamed_sphere_list(renderer, oracle64):
+    """Lights on a scene with more spheres than stay resident in LDS: the general kernel streams the sphere
+    list through LDS in tiles shared by the workgroup."""
+    from raytracer_amd.api import FLAG_DIRECT_LIGHT
+
+    scene = scenes.grid_scene(72, 72)  # 5185 spheres
+    scene.lights = scenes.small_scene(phong=1).lights.copy()
+    scene.lights["position"][0] = (0.0, 0.0, 30.0)
+    renderer.set_scene(scene)
+    W, H, spp, depth = 64, 36, 16, 8
+    p = RenderParams(W, H, samples_per_pixel=spp, max_depth=depth, seed=2, flags=FLAG_DIRECT_LIGHT)
+    rgba, accum, rays = renderer.render_host(p, want_accum=True)
+    ra, acc_a, rays_a = oracle64.render(scene, W, H, spp, depth, seed=2, direct_light=True)
+    rb, _, _ = oracle64.render(scene, W, H, spp, depth, seed=3, direct_light=True)
+    assert psnr(rgba[:, :, :3], ra[:, :, :3]) >= psnr(ra[:, :, :3], rb[:, :, :3]) - 0.5
+    assert abs(rays - rays_a) <= 0.01 * rays_a
+    lin = accum[:, :, :3].astype(np.float64).mean(axis=(0, 1)) / spp
+    assert np.allclose(lin, acc_a.mean(axis=(0, 1)) / spp, rtol=1e-2)
