@@ -713,3 +713,50 @@ def test_general_kernel_with_a_streamed_sphere_list(renderer, oracle64):
     assert abs(rays - rays_a) <= 0.01 * rays_a
     lin = accum[:, :, :3].astype(np.float64).mean(axis=(0, 1)) / spp
     assert np.allclose(lin, acc_a.mean(axis=(0, 1)) / spp, rtol=1e-2)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_general_first_hit_on_random_primitive_soups(renderer, oracle64, seed):
+    """Random mixtures of every primitive kind -- overlapping, some selected, negative radii, degenerate
+    polygons, rays parallel to box faces -- with and without the halo pass: the refined first hit equals the
+    oracle's decision bit for bit."""
+    rng = np.random.default_rng(seed)
+    b = scenes._Builder()
+    m = b.lambertian((0.5, 0.5, 0.5))
+    n = int(rng.integers(6, 40))
+    for i in range(n):
+        kind = int(rng.integers(0, 4))
+        c = rng.uniform(-4, 4, 3)
+        if kind == 0:
+            b.sphere(c, float(rng.uniform(0.1, 1.5)) * (-1 if rng.random() < 0.15 else 1), m)
+        elif kind == 1:
+            b.plane(c * 2, rng.normal(size=3), m)
+        elif kind == 2:
+            b.cube(c, rng.uniform(0.1, 1.2, 3), m)
+        else:
+            nv = int(rng.integers(2, 7))  # two vertices: a polygon that is never hit
+            ang = np.sort(rng.uniform(0, 2 * np.pi, nv))
+            u, v = np.linalg.qr(rng.normal(size=(3, 2)))[0].T
+            rad = rng.uniform(0.3, 1.5)
+            b.polygon([c + rad * (np.cos(a) * u + np.sin(a) * v) for a in ang], m)
+        if rng.random() < 0.3:
+            b.select(i)
+    scene = b.build("soup", scenes.make_camera())
+    scene.needs_general = True
+    renderer.set_scene(scene)
+    N = 4000
+    org = rng.uniform(-6, 6, (N, 3)).astype(np.float32)
+    dirs = (rng.normal(size=(N, 3)) * rng.uniform(0.1, 4.0, (N, 1))).astype(np.float32)
+    dirs[:200, 0] = 0.0  # rays inside an axis plane: the slab test's parallel branch
+    dirs[100:300, 1] = 0.0
+    for es in (False, True):
+        ids, t, nrm, front, exp = renderer.first_hit(org, dirs, tmin=TMIN, refine=True, expanded_state=es,
+                                                     want_expanded=True)
+        oid, ot, onrm, ofront, _, oexp = oracle64.first_hit(scene, org, dirs, tmin=TMIN, general=True,
+                                                            expanded_state=es, want_expanded=True)
+        assert np.array_equal(ids, oid) and np.array_equal(exp, oexp)
+        hit = oid >= 0
+        assert hit.mean() > 0.3
+        assert np.array_equal(front[hit], ofront[hit])
+        assert np.all(np.abs(t[hit] - ot[hit]) <= 1e-5 * np.abs(ot[hit]) + 1e-7)
+        assert np.max(np.abs(nrm[hit] - onrm[hit])) <= 1e-5
