@@ -412,24 +412,25 @@ def _downsample(img, fy, fx):
     return img[:h, :w].reshape(h // fy, fy, w // fx, fx, -1).mean(axis=(1, 3))
 
 
-@pytest.mark.parametrize("name,scene_name,W,H,spp,depth,rays_lo,rays_hi",
-                         [("c1", "small", 400, 225, 10, 10, 1.9, 2.4),
-                          ("c2", "small", 1920, 1080, 100, 50, 1.9, 2.4),
-                          ("c3", "random_spheres", 1200, 675, 500, 50, 1.95, 2.15)])
-def test_full_size_configs(renderer, oracle64, name, scene_name, W, H, spp, depth, rays_lo, rays_hi):
+@pytest.mark.parametrize("name,scene_name,W,H,spp,depth,rays_lo,rays_hi,f",
+                         [("c1", "small", 400, 225, 10, 10, 1.9, 2.4, 5),
+                          ("c2", "small", 1920, 1080, 100, 50, 1.9, 2.4, 5),
+                          ("c3", "random_spheres", 1200, 675, 500, 50, 1.95, 2.15, 5),
+                          ("c4", "random_spheres", 3840, 2160, 1000, 50, 1.95, 2.15, 8),
+                          ("c5", "grid10k", 3840, 2160, 256, 50, 3.8, 4.3, 12)])
+def test_full_size_configs(renderer, oracle64, name, scene_name, W, H, spp, depth, rays_lo, rays_hi, f):
     """The benchmark configurations at full size: reproducible, every pixel written, rays per sample in the
     oracle's range, and the box-filtered frame equal (within noise) to an oracle render of the same
-    scene at 1/5 of the resolution (the camera model has no resolution-dependent term)."""
+    scene at 1/f of the resolution (the camera model has no resolution-dependent term)."""
     scene = scenes.by_name(scene_name)
     renderer.set_scene(scene)
     p = RenderParams(W, H, samples_per_pixel=spp, max_depth=depth, seed=11)
     a, acc, rays = renderer.render_host(p, want_accum=True)
     assert np.all(a[:, :, 3] == 255) and np.all(acc[:, :, 3] == spp)
     assert rays_lo <= rays / (W * H * spp) <= rays_hi
-    if name != "c3":  # c3 twice is the benchmark itself; one repeat is enough for the smaller ones
+    if name in ("c1", "c2"):  # the larger ones twice are the benchmark itself
         b, _, rays_b = renderer.render_host(p)
         assert np.array_equal(a, b) and rays == rays_b
-    f = 5
     small_w, small_h = W // f, H // f
     o_spp = max(16, min(spp, 6000000 // (small_w * small_h * 3)))
     _, o_acc, o_rays = oracle64.render(scene, small_w, small_h, o_spp, depth, seed=3)
