@@ -1,4 +1,11 @@
-"""Tuning aid: event counters of a -DRT_STATS build (tools/v_stats.so) for one render of a scene."""
+"""Tuning aid: event counters of a -DRT_STATS build for one render of a scene.
+
+Build the instrumented library first (add -DRT_STATS_TIMES_ONLY to keep only the per-wave timing, which
+does not slow the kernel down):
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -fvisibility=hidden -DRT_STATS \
+        -o tools/v_stats.so raytracer_amd/csrc/rt_amd.hip
+usage: dbg_stats.py [scene W H spp depth]
+"""
 import ctypes as C, os, sys
 sys.path.insert(0, '.')
 os.environ["RT_AMD_LIB"] = os.path.abspath(os.environ.get("STATS_LIB", "tools/v_stats.so"))
