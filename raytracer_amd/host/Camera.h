@@ -76,6 +76,14 @@ public:
     // expectation as the reference's S-way branching at every hit, without its S^depth ray tree.
     void render(const SceneManager &sceneManager, const std::pair<int, int> screenResolution,
                 std::vector<RTPixelColor> &outputBufer);
+    // same render (the reference's parallel / serial pixel loops, inc/Camera.h:72-84)
+    void renderParallel(const SceneManager &sceneManager, const std::pair<int, int> screenResolution,
+                        std::vector<RTPixelColor> &outputBufer);
+    void renderSerial(const SceneManager &sceneManager, const std::pair<int, int> screenResolution,
+                      std::vector<RTPixelColor> &outputBufer);
+    // one pixel of the frame (inc/Camera.h:86-91); equals that pixel of render()
+    RTPixelColor renderPixelColor(const SceneManager &sceneManager, const int pixelId,
+                                  const std::pair<int, int> screenResolution);
 
     gm::IVec3f direction() const;
     gm::IPoint3 center() const;
@@ -85,6 +93,8 @@ public:
 
 private:
     void updateViewPort();
+    void renderStrips(const SceneManager &sceneManager, int W, int H, int stripFirst, int stripStride,
+                      RTPixelColor *rgba);
 };
 
 std::ostream &operator<<(std::ostream &stream, const Camera &camera);

@@ -70,14 +70,10 @@ void put3(float *dst, const gm::IVec3f &v) {
 }
 } // namespace
 
-void Camera::render(const SceneManager &sceneManager, const std::pair<int, int> screenResolution,
-                    std::vector<RTPixelColor> &outputBufer) {
-    const int W = screenResolution.first, H = screenResolution.second;
-    if (W <= 0 || H <= 0) throw BackendError(RT_ERR_INVALID, "Camera::render: resolution must be positive");
-    // the reference asserts this (src/Camera.cpp:76); a short buffer cannot be rendered into
-    if ((size_t)W * (size_t)H != outputBufer.size())
-        throw BackendError(RT_ERR_INVALID, "Camera::render: outputBufer.size() != width*height");
-
+// Uploads scene and pose and renders strips strip_first, strip_first + strip_stride, ... compactly into
+// `rgba` (rt_output_rows x width pixels).
+void Camera::renderStrips(const SceneManager &sceneManager, int W, int H, int stripFirst, int stripStride,
+                          RTPixelColor *rgba) {
     // flatten first: a scene the GPU path cannot take is rejected before any device is touched
     const FlatScene flat = flattenScene(sceneManager, renderProperties.enableLDirect);
 
@@ -107,11 +103,49 @@ void Camera::render(const SceneManager &sceneManager, const std::pair<int, int> 
     p.seed = seed;
     // lights feed Camera::computeDirectLighting (reference src/Camera.cpp:161-178) when enableLDirect is set
     p.flags = flat.lights.empty() ? 0u : (uint32_t)RT_FLAG_DIRECT_LIGHT;
-    p.strip_first = 0;
-    p.strip_stride = 1;
+    p.strip_first = stripFirst;
+    p.strip_stride = stripStride;
     static_assert(sizeof(RTPixelColor) == 4, "RTPixelColor must be 4 bytes of RGBA");
-    rc = rt_render_host(ctx_, &p, reinterpret_cast<uint8_t *>(outputBufer.data()), nullptr, &lastRaysTraced);
+    rc = rt_render_host(ctx_, &p, reinterpret_cast<uint8_t *>(rgba), nullptr, &lastRaysTraced);
     if (rc != RT_OK) fail(ctx_, rc, "rt_render_host");
+}
+
+void Camera::render(const SceneManager &sceneManager, const std::pair<int, int> screenResolution,
+                    std::vector<RTPixelColor> &outputBufer) {
+    const int W = screenResolution.first, H = screenResolution.second;
+    if (W <= 0 || H <= 0) throw BackendError(RT_ERR_INVALID, "Camera::render: resolution must be positive");
+    // the reference asserts this (src/Camera.cpp:76); a short buffer cannot be rendered into
+    if ((size_t)W * (size_t)H != outputBufer.size())
+        throw BackendError(RT_ERR_INVALID, "Camera::render: outputBufer.size() != width*height");
+    renderStrips(sceneManager, W, H, 0, 1, outputBufer.data());
+}
+
+// The reference's two loops over pixels (src/Camera.cpp:69-103) differ in threading and in whether the
+// generator is re-seeded per pixel; both are the same GPU render here.
+void Camera::renderParallel(const SceneManager &sceneManager, const std::pair<int, int> screenResolution,
+                            std::vector<RTPixelColor> &outputBufer) {
+    render(sceneManager, screenResolution, outputBufer);
+}
+
+void Camera::renderSerial(const SceneManager &sceneManager, const std::pair<int, int> screenResolution,
+                          std::vector<RTPixelColor> &outputBufer) {
+    render(sceneManager, screenResolution, outputBufer);
+}
+
+// One pixel (reference src/Camera.cpp:105-122): the 8-row strip that holds it is rendered and the pixel
+// picked; its bytes equal the same pixel of a full render (random streams are keyed on the pixel id).
+RTPixelColor Camera::renderPixelColor(const SceneManager &sceneManager, const int pixelId,
+                                      const std::pair<int, int> screenResolution) {
+    const int W = screenResolution.first, H = screenResolution.second;
+    if (W <= 0 || H <= 0) throw BackendError(RT_ERR_INVALID, "Camera::renderPixelColor: resolution must be positive");
+    if (pixelId < 0 || (long long)pixelId >= (long long)W * H)
+        throw BackendError(RT_ERR_INVALID, "Camera::renderPixelColor: pixelId outside the frame");
+    const int x = pixelId % W, y = pixelId / W;
+    const int strips = (H + RT_STRIP_ROWS - 1) / RT_STRIP_ROWS;
+    std::vector<RTPixelColor> strip((size_t)RT_STRIP_ROWS * (size_t)W);
+    // strip_first = the pixel's strip, stride = number of strips: exactly one strip is rendered
+    renderStrips(sceneManager, W, H, y / RT_STRIP_ROWS, strips, strip.data());
+    return strip[(size_t)(y % RT_STRIP_ROWS) * (size_t)W + (size_t)x];
 }
 
 } // namespace rtamd

@@ -10,6 +10,8 @@
 //        host_demo --pick <scene> <W> <H> <expanded 0|1>
 //                                                  SceneManager::hitClosest for the W x H pixel-centre rays of the
 //                                                  default camera; prints "id t nx ny nz front expanded object" per ray
+//        host_demo --pixels <scene> <W> <H> <spp> <depth>
+//                                                  renderPixelColor / renderParallel / renderSerial against render
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -183,6 +185,42 @@ int main(int argc, char **argv) {
             std::fprintf(stderr, "hitClosest failed (%d): %s\n", e.status(), e.what());
             return 1;
         }
+        return 0;
+    }
+    if (argc >= 7 && !std::strcmp(argv[1], "--pixels")) {
+        SceneManager scene;
+        RTMaterialManager mm;
+        const bool lit = buildScene(argv[2], scene, mm);
+        const int W = atoi(argv[3]), H = atoi(argv[4]);
+        Camera cam;
+        cam.renderProperties.samplesPerPixel = atoi(argv[5]);
+        cam.renderProperties.samplesPerScatter = 1;
+        cam.renderProperties.maxRayDepth = atoi(argv[6]);
+        cam.renderProperties.enableLDirect = lit;
+        cam.seed = 5;
+        try {
+            std::vector<RTPixelColor> a((size_t)W * H), b((size_t)W * H), c((size_t)W * H);
+            cam.render(scene, {W, H}, a);
+            cam.renderParallel(scene, {W, H}, b);
+            cam.renderSerial(scene, {W, H}, c);
+            if (std::memcmp(a.data(), b.data(), a.size() * 4) || std::memcmp(a.data(), c.data(), a.size() * 4)) return 3;
+            const int ids[] = {0, W - 1, W * (H / 2) + W / 2, W * (H - 1), W * H - 1, W * 9 + 3};
+            for (int id : ids) {
+                if (id >= W * H) continue;
+                RTPixelColor px = cam.renderPixelColor(scene, id, {W, H});
+                if (std::memcmp(&px, &a[(size_t)id], 4)) {
+                    std::fprintf(stderr, "pixel %d differs\n", id);
+                    return 4;
+                }
+            }
+            bool threw = false;
+            try { cam.renderPixelColor(scene, W * H, {W, H}); } catch (const BackendError &e) { threw = e.status() == -1; }
+            if (!threw) return 5;
+        } catch (const BackendError &e) {
+            std::fprintf(stderr, "render failed (%d): %s\n", e.status(), e.what());
+            return 1;
+        }
+        std::printf("pixels ok\n");
         return 0;
     }
     if (argc < 6) {

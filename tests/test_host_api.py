@@ -194,3 +194,12 @@ def test_scene_manager_hit_closest_matches_oracle(oracle64, expanded):
     assert np.array_equal(rows[hit, 6].astype(int), ofront[hit])
     assert np.array_equal(rows[:, 7].astype(int), oexp)
     assert (oexp.sum() > 0) == bool(expanded)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,W,H", [("small", 50, 29), ("mixed_lit", 33, 7)])
+def test_render_pixel_color_and_render_variants(name, W, H):
+    """Camera::renderPixelColor (reference src/Camera.cpp:105-122) returns the bytes render() puts at that
+    pixel; renderParallel and renderSerial are the same render."""
+    r = subprocess.run([_need_demo(), "--pixels", name, str(W), str(H), "12", "8"], capture_output=True, text=True)
+    assert r.returncode == 0 and "pixels ok" in r.stdout, r.stdout + r.stderr
