@@ -56,11 +56,11 @@ struct Interval {
     bool contains(double x) const { return min <= x && x <= max; }
     bool surrounds(double x) const { return min < x && x < max; }
     double clamp(double x) const { return x < min ? min : (x > max ? max : x); }
-    static Interval empty() { return Interval(); }
-    static Interval universe() {
-        return Interval(-std::numeric_limits<double>::infinity(), +std::numeric_limits<double>::infinity());
-    }
+    static const Interval empty, universe; // as in the reference (inc/RTGeometry.h:89)
 };
+inline const Interval Interval::empty = Interval();
+inline const Interval Interval::universe =
+    Interval(-std::numeric_limits<double>::infinity(), +std::numeric_limits<double>::infinity());
 
 } // namespace rtamd
 #endif
