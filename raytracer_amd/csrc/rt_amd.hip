@@ -38,7 +38,10 @@ constexpr int RESIDENT_MAX = 4096;           // spheres kept resident in LDS (80
 constexpr int STREAM_QUADS = 512;            // quads (4 spheres, 80 B) per streamed LDS tile (40 KiB)
 constexpr int SLOT_WORDS = 3 * MAX_TILE_PX;  // one tile slot's accumulators: r, g, b planes of 64-bit sums
 constexpr int WAVE_LDS_WORDS = 2 * SLOT_WORDS + 8; // two slots and their tile descriptors
-constexpr size_t ACC_BYTES = WAVES_PER_WG * WAVE_LDS_WORDS * sizeof(unsigned long long); // per-wave LDS state
+constexpr size_t ACC_BYTES = WAVES_PER_WG * WAVE_LDS_WORDS * sizeof(unsigned long long); // per-wave accumulators
+// per-wave candidate queue and closest-hit slots of the deferred sphere decisions (rt_device.h)
+constexpr size_t CQ_BYTES = WAVES_PER_WG * (CAND_CAP * sizeof(unsigned) + 64 * sizeof(unsigned long long));
+constexpr size_t WAVE_STATE_BYTES = ACC_BYTES + CQ_BYTES;
 
 // Radiance sums are kept in signed 40.24 fixed point: integer addition is exact, so a pixel's sum
 // does not depend on the order in which its samples finish -- which changes with the tile that
@@ -109,7 +112,6 @@ __device__ __forceinline__ void scan_lds(const float4 *lds, const float4 *lds_r2
 // order, so the only safe wait is lgkmcnt(0); the loop keeps exactly one load in
 // flight: wait for quad q, request quad q+1, test quad q.
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
 template <int BYTE_OFF>
 __device__ __forceinline__ u32x16 sload_quad(const float4 *p) {
@@ -117,60 +119,55 @@ __device__ __forceinline__ u32x16 sload_quad(const float4 *p) {
     asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "i"(BYTE_OFF) : "memory");
     return v;
 }
-// squared radii of two consecutive quads
-template <int BYTE_OFF>
-__device__ __forceinline__ u32x8 sload_r2(const float4 *p) {
-    u32x8 v;
-    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(p), "i"(BYTE_OFF) : "memory");
-    return v;
-}
-__device__ __forceinline__ void swait_quads(u32x16 &a, u32x16 &b, u32x8 &r) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(r)::"memory");
+__device__ __forceinline__ void swait_quads(u32x16 &a, u32x16 &b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory");
 }
 __device__ __forceinline__ float4 word(const u32x16 &v, int k) {
     return make_float4(__uint_as_float(v[4 * k]), __uint_as_float(v[4 * k + 1]), __uint_as_float(v[4 * k + 2]),
                        __uint_as_float(v[4 * k + 3]));
 }
-__device__ __forceinline__ float4 word(const u32x8 &v, int k) {
-    return make_float4(__uint_as_float(v[4 * k]), __uint_as_float(v[4 * k + 1]), __uint_as_float(v[4 * k + 2]),
-                       __uint_as_float(v[4 * k + 3]));
-}
-
 // nquads is even (the list is padded with never-hit spheres) and four spare quads follow
 // it, so the read-ahead never leaves the arrays.  Two quads are requested while two are
 // tested; a list of two quads is one request and one wait.
-__device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, const float4 *__restrict__ g2, int nquads,
-                                            const RayK &r, V3 o, V3 dh, float tmin, int self_id, float &best_t,
-                                            int &best_id) {
+// Called by the whole wave, lanes without a ray included (their threshold is +inf): what passes
+// the filter is queued and decided in full batches (rt_device.h), which needs every lane.
+__device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, int nquads, const RayK &r, V3 o, V3 dh,
+                                            float tmin, int self_id, int lane, const CandQ &cq,
+                                            const float4 *__restrict__ sph, float &best_t, int &best_id) {
+    cq.slot[lane] = NO_HIT_KEY;
+    int count = 0; // queue fill, wave-uniform
     u32x16 A0 = sload_quad<0>(g), A1 = sload_quad<64>(g);
-    u32x8 RA = sload_r2<0>(g2);
     __builtin_amdgcn_sched_barrier(0);
     if (nquads <= 2) {
-        swait_quads(A0, A1, RA);
-        test_quad2(r, o, dh, word(A0, 0), word(A0, 1), word(A0, 2), word(A0, 3), word(RA, 0), word(A1, 0), word(A1, 1),
-                   word(A1, 2), word(A1, 3), word(RA, 1), tmin, 0, self_id, best_t, best_id);
+        swait_quads(A0, A1);
+        queue_quad2(r, word(A0, 0), word(A0, 1), word(A0, 2), word(A0, 3), word(A1, 0), word(A1, 1), word(A1, 2),
+                    word(A1, 3), 0, lane, cq, count, o, dh, tmin, self_id, sph);
         nquads = 0; // skips the loop below
     }
 #pragma unroll 1
     for (int q = 0; q < nquads; q += 4) {
-        swait_quads(A0, A1, RA);
+        swait_quads(A0, A1);
         u32x16 B0 = sload_quad<128>(g), B1 = sload_quad<192>(g);
-        u32x8 RB = sload_r2<32>(g2);
         __builtin_amdgcn_sched_barrier(0); // keep the requests ahead of the arithmetic they overlap with
-        test_quad2(r, o, dh, word(A0, 0), word(A0, 1), word(A0, 2), word(A0, 3), word(RA, 0), word(A1, 0), word(A1, 1),
-                   word(A1, 2), word(A1, 3), word(RA, 1), tmin, 4 * q, self_id, best_t, best_id);
-        swait_quads(B0, B1, RB);
+        queue_quad2(r, word(A0, 0), word(A0, 1), word(A0, 2), word(A0, 3), word(A1, 0), word(A1, 1), word(A1, 2),
+                    word(A1, 3), 4 * q, lane, cq, count, o, dh, tmin, self_id, sph);
+        swait_quads(B0, B1);
         g += 16; // four quads
-        g2 += 4;
         A0 = sload_quad<0>(g);
         A1 = sload_quad<64>(g);
-        RA = sload_r2<0>(g2);
         __builtin_amdgcn_sched_barrier(0);
         if (q + 2 < nquads)
-            test_quad2(r, o, dh, word(B0, 0), word(B0, 1), word(B0, 2), word(B0, 3), word(RB, 0), word(B1, 0),
-                       word(B1, 1), word(B1, 2), word(B1, 3), word(RB, 1), tmin, 4 * q + 8, self_id, best_t, best_id);
+            queue_quad2(r, word(B0, 0), word(B0, 1), word(B0, 2), word(B0, 3), word(B1, 0), word(B1, 1), word(B1, 2),
+                        word(B1, 3), 4 * q + 8, lane, cq, count, o, dh, tmin, self_id, sph);
     }
-    swait_quads(A0, A1, RA); // drain the read-ahead before the registers are reused
+    swait_quads(A0, A1); // drain the read-ahead before the registers are reused
+    while (count > 0) resolve_batch(cq, count, min(count, 64), lane, o, dh, tmin, self_id, sph);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const unsigned long long key = cq.slot[lane];
+    if (key != NO_HIT_KEY) {
+        best_t = __uint_as_float((unsigned)(key >> 32));
+        best_id = (int)(unsigned)key;
+    }
 }
 
 // Camera::genRay, src/Camera.cpp:124-135: jittered point on the 1x1 viewport.
@@ -261,7 +258,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
     // per-wave state first (two accumulator slots of 3 channels x 64 pixels and their tile
     // descriptors), then the sphere words
     unsigned long long *acc_all = reinterpret_cast<unsigned long long *>(smem);
-    float4 *lds_sph = reinterpret_cast<float4 *>(smem + ACC_BYTES);
+    float4 *lds_sph = reinterpret_cast<float4 *>(smem + WAVE_STATE_BYTES);
     // the squared radii follow the pair words of the resident list / of one streamed tile
     float4 *lds_r2 = lds_sph + 4 * (SRC == SRC_LDS_STREAMED ? STREAM_QUADS : p.n_quads);
 
@@ -269,6 +266,9 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
     const int wave = threadIdx.x >> 6;
     unsigned long long *acc = acc_all + wave * WAVE_LDS_WORDS;
     int *desc = reinterpret_cast<int *>(acc + 2 * SLOT_WORDS); // slot s: desc[8 s ...] = x0, y0, vw, vh, row0
+    CandQ cq;
+    cq.slot = reinterpret_cast<unsigned long long *>(smem + ACC_BYTES) + wave * 64;
+    cq.ent = reinterpret_cast<unsigned *>(smem + ACC_BYTES + WAVES_PER_WG * 64 * sizeof(unsigned long long)) + wave * CAND_CAP;
 
     const int nquads = p.n_quads; // groups of four spheres, padding included
     if (SRC == SRC_LDS_RESIDENT) {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         float best_t = __builtin_inff(); // in units of |d|
         int best_id = -1;
         const float tmin = TMIN * pt.len;
-        const RayK rk = make_rayk(pt.o, pt.dh);
+        RayK rk = make_rayk(pt.o, pt.dh);
         if (SRC == SRC_LDS_STREAMED) {
             for (int base = 0; base < nquads; base += STREAM_QUADS) {
                 int cnt = min(STREAM_QUADS, nquads - base);
@@ -351,7 +351,9 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         } else if (SRC == SRC_LDS_RESIDENT) {
             if (active) scan_lds(lds_sph, lds_r2, nquads, 0, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
         } else {
-            if (active) scan_scalar(sc.pairs, sc.r2q, nquads, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
+            // the whole wave scans: a lane without a ray passes no filter
+            rk.thr = active ? rk.thr : __builtin_inff();
+            scan_scalar(sc.pairs, nquads, rk, pt.o, pt.dh, tmin, pt.self_id, lane, cq, sc.sph, best_t, best_id);
         }
 
         // ---- shade (Camera::getRayColor, src/Camera.cpp:137-157) ----
@@ -1131,15 +1133,16 @@ RT_API int rt_create(int device, rt_ctx **out) {
         return RT_ERR_HIP;
     }
     // allow the render kernels their dynamic LDS budget
-    size_t lds_max = ACC_BYTES + (size_t)RESIDENT_MAX / 4 * 5 * sizeof(float4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_RESIDENT, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_STREAMED, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_RESIDENT, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_LDS_STREAMED, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    size_t lds_max = WAVE_STATE_BYTES + (size_t)RESIDENT_MAX / 4 * 5 * sizeof(float4);
+    const void *lds_kernels[] = {reinterpret_cast<const void *>(&render_kernel<SRC_LDS_RESIDENT, false>),
+                                 reinterpret_cast<const void *>(&render_kernel<SRC_LDS_STREAMED, false>),
+                                 reinterpret_cast<const void *>(&render_kernel<SRC_LDS_RESIDENT, true>),
+                                 reinterpret_cast<const void *>(&render_kernel<SRC_LDS_STREAMED, true>)};
+    for (const void *k : lds_kernels)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess) {
+            delete ctx;
+            return RT_ERR_HIP;
+        }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cus = prop.multiProcessorCount;
@@ -1426,7 +1429,7 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 256, st));
     // the general kernel serves lights, the non-sphere primitives and the selection halo
     const bool full = k.n_lights > 0 || ctx->n_others > 0 || ctx->n_halo > 0;
-    size_t lds = ACC_BYTES;
+    size_t lds = WAVE_STATE_BYTES;
     int src = SRC_SCALAR;
     // The scalar-load scan keeps loads in flight across compiler-scheduled code, which is only safe
     // while none of their registers is spilled; the general kernel is too register-hungry for that

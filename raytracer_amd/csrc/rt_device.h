@@ -155,25 +155,31 @@ __device__ __forceinline__ void stat_lanes(int k) {
 // `self_id` names the sphere whose surface the ray starts on (-1: none): its constant
 // term is exactly zero in real arithmetic but rounding noise of size ulp(|oc|)*r in
 // floats, so it is skipped here and handled in closed form by self_hit().
+// Returns the root the reference would take, in units of |d| (a NaN or a value outside
+// (tmin, .) when there is none).
+__device__ __forceinline__ float sphere_root(V3 o, V3 dh, float cx, float cy, float cz, float r2, float tmin) {
+    float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
+    float hb = fmaf(ocx, dh.x, fmaf(ocy, dh.y, ocz * dh.z));
+    float px = fmaf(-hb, dh.x, ocx), py = fmaf(-hb, dh.y, ocy), pz = fmaf(-hb, dh.z, ocz);
+    float disc = fmaf(-px, px, fmaf(-py, py, fmaf(-pz, pz, r2)));
+    // a negative discriminant needs no branch: its square root is NaN, and no comparison the
+    // callers make holds for a NaN
+    float c = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -r2)));
+    float sq = __builtin_amdgcn_sqrtf(disc);
+    float q = -(hb + __builtin_copysignf(sq, hb)); // |q| = |hb| + sq
+    float r1 = c * __builtin_amdgcn_rcpf(q);
+    float t_near = fminf(q, r1), t_far = fmaxf(q, r1);
+    // the reference takes the nearer root if it lies in (tmin, closest), else the farther one if
+    // that does; a nearer root >= closest rules the farther one out as well
+    return t_near > tmin ? t_near : t_far;
+}
+
 __device__ __forceinline__ void resolve_hit(V3 o, V3 dh, float cx, float cy, float cz, float r2, float f, float thr,
                                             float tmin, int idx, int self_id, float &best_t, int &best_id) {
     if (f >= thr) {
         RT_STAT(4);       // sphere bodies entered (per wave)
         RT_STAT_LANES(5); // ... (per lane)
-        float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
-        float hb = fmaf(ocx, dh.x, fmaf(ocy, dh.y, ocz * dh.z));
-        float px = fmaf(-hb, dh.x, ocx), py = fmaf(-hb, dh.y, ocy), pz = fmaf(-hb, dh.z, ocz);
-        float disc = fmaf(-px, px, fmaf(-py, py, fmaf(-pz, pz, r2)));
-        // a negative discriminant needs no branch: its square root is NaN, and no comparison below
-        // holds for a NaN
-        float c = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -r2)));
-        float sq = __builtin_amdgcn_sqrtf(disc);
-        float q = -(hb + __builtin_copysignf(sq, hb)); // |q| = |hb| + sq
-        float r1 = c * __builtin_amdgcn_rcpf(q);
-        float t_near = fminf(q, r1), t_far = fmaxf(q, r1);
-        // the reference takes the nearer root if it lies in (tmin, best_t), else the farther
-        // one if that does; a nearer root >= best_t rules the farther one out as well
-        float cand = t_near > tmin ? t_near : t_far;
+        float cand = sphere_root(o, dh, cx, cy, cz, r2, tmin);
         if (cand > tmin && cand < best_t && idx != self_id) {
             RT_STAT_LANES(6); // closest-hit updates (per lane)
             best_t = cand;
@@ -248,8 +254,112 @@ __device__ __forceinline__ void test_quad2(const RayK &r, V3 o, V3 dh, float4 A0
     // one test for both groups first: it keeps the two chains together ahead of the branch
     float m = fmaxf(fmaxf(fmaxf(a.F0.x, a.F0.y), fmaxf(a.F1.x, a.F1.y)), fmaxf(fmaxf(b.F0.x, b.F0.y), fmaxf(b.F1.x, b.F1.y)));
     if (m >= r.thr) {
+        RT_STAT(7); // groups of eight entered (per wave)
         resolve_quad(r, o, dh, A0, B0, A1, B1, Ra, a, tmin, idx, self_id, best_t, best_id);
         resolve_quad(r, o, dh, C0, D0, C1, D1, Rb, b, tmin, idx + 4, self_id, best_t, best_id);
+    }
+}
+
+// ---- deferred decisions: the wave's candidate queue --------------------------------------
+// Inside the scan a sphere passes the filter for about one lane in six, so deciding it on the spot
+// runs the whole decision with most lanes masked off.  The scalar-load scan therefore only RECORDS
+// what passed: every (lane, sphere) pair goes into a queue in LDS (ballot + prefix count), and the
+// queue is worked off 64 entries at a time with every lane busy: lane j takes entry j, fetches the
+// ray of the entry's lane through ds_bpermute and the sphere from memory, and folds the root into
+// the ray's closest hit by a 64-bit minimum in LDS on (t bits << 32 | sphere index): the smallest
+// t wins and, on equal t, the lowest index, which is what SceneManager::hitClosest's strict '<' in
+// insertion order gives (src/RayTracer.cpp:77-82).  A root is positive (> tmin > 0), so its bits
+// order like its value.
+constexpr int CAND_CAP = 64 * 9; // a group of eight appends at most 8*64 entries to a queue holding fewer than 64
+constexpr unsigned long long NO_HIT_KEY = ~0ull;
+
+struct CandQ {
+    unsigned *ent;            // CAND_CAP entries: lane | sphere << 6
+    unsigned long long *slot; // per lane of the wave: the closest hit so far, NO_HIT_KEY = none
+};
+
+__device__ __forceinline__ int lane_rank(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Must be called by the whole wave (it ballots).
+__device__ __forceinline__ void push_cand(const CandQ &cq, int &count, float f, float thr, int idx, int lane) {
+    const bool pass = f >= thr;
+    const unsigned long long m = __ballot(pass);
+    if (m) {
+        RT_STAT(4);
+        if (pass) {
+            RT_STAT_LANES(5);
+            cq.ent[count + lane_rank(m)] = (unsigned)lane | ((unsigned)idx << 6);
+        }
+        count += (int)__popcll(m);
+    }
+}
+
+__device__ __forceinline__ float lane_fetch(int byte_addr, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+// Works off the last n (<= 64) entries of the queue.  Whole wave, all lanes enabled: ds_bpermute
+// returns nothing from a disabled lane.
+__device__ __forceinline__ void resolve_batch(const CandQ &cq, int &count, int n, int lane, V3 o, V3 dh, float tmin,
+                                              int self_id, const float4 *__restrict__ sph) {
+    const int head = count - n;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const unsigned e = cq.ent[head + min(lane, n - 1)];
+    const int src = (int)(e & 63u) << 2;
+    const int s = (int)(e >> 6);
+    const float4 sp = sph[s];
+    const V3 ro = mk(lane_fetch(src, o.x), lane_fetch(src, o.y), lane_fetch(src, o.z));
+    const V3 rd = mk(lane_fetch(src, dh.x), lane_fetch(src, dh.y), lane_fetch(src, dh.z));
+    const float rt = lane_fetch(src, tmin);
+    const int rself = __builtin_amdgcn_ds_bpermute(src, self_id);
+    const float cand = sphere_root(ro, rd, sp.x, sp.y, sp.z, sp.w * sp.w, rt);
+    if (lane < n && cand > rt && cand < __builtin_inff() && s != rself) {
+        RT_STAT_LANES(6);
+        atomicMin(&cq.slot[e & 63u], ((unsigned long long)__float_as_uint(cand) << 32) | (unsigned long long)(unsigned)s);
+    }
+    count = head;
+}
+
+// Filter of two groups of four spheres (as test_quad2); what passes is queued, not decided.
+__device__ __forceinline__ void queue_quad2(const RayK &r, float4 A0, float4 B0, float4 A1, float4 B1, float4 C0,
+                                            float4 D0, float4 C1, float4 D1, int idx, int lane, const CandQ &cq,
+                                            int &count, V3 o, V3 dh, float tmin, int self_id,
+                                            const float4 *__restrict__ sph) {
+    f2 x0 = {A0.x, A0.y}, y0 = {A0.z, A0.w}, z0 = {B0.x, B0.y}, q0 = {B0.z, B0.w};
+    f2 x1 = {A1.x, A1.y}, y1 = {A1.z, A1.w}, z1 = {B1.x, B1.y}, q1 = {B1.z, B1.w};
+    f2 x2 = {C0.x, C0.y}, y2 = {C0.z, C0.w}, z2 = {D0.x, D0.y}, q2 = {D0.z, D0.w};
+    f2 x3 = {C1.x, C1.y}, y3 = {C1.z, C1.w}, z3 = {D1.x, D1.y}, q3 = {D1.z, D1.w};
+    QuadF a, b;
+    RT_QUAD_STEP(a, x0 * r.dx, x1 * r.dx);
+    RT_QUAD_STEP(b, x2 * r.dx, x3 * r.dx);
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(y0, r.dy, a.F0), __builtin_elementwise_fma(y1, r.dy, a.F1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(y2, r.dy, b.F0), __builtin_elementwise_fma(y3, r.dy, b.F1));
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(z0, r.dz, a.F0), __builtin_elementwise_fma(z1, r.dz, a.F1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(z2, r.dz, b.F0), __builtin_elementwise_fma(z3, r.dz, b.F1));
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(a.F0, a.F0, q0), __builtin_elementwise_fma(a.F1, a.F1, q1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(b.F0, b.F0, q2), __builtin_elementwise_fma(b.F1, b.F1, q3));
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(x0, r.kx, a.F0), __builtin_elementwise_fma(x1, r.kx, a.F1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(x2, r.kx, b.F0), __builtin_elementwise_fma(x3, r.kx, b.F1));
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(y0, r.ky, a.F0), __builtin_elementwise_fma(y1, r.ky, a.F1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(y2, r.ky, b.F0), __builtin_elementwise_fma(y3, r.ky, b.F1));
+    RT_QUAD_STEP(a, __builtin_elementwise_fma(z0, r.kz, a.F0), __builtin_elementwise_fma(z1, r.kz, a.F1));
+    RT_QUAD_STEP(b, __builtin_elementwise_fma(z2, r.kz, b.F0), __builtin_elementwise_fma(z3, r.kz, b.F1));
+    // four three-way maxima decide for the eight spheres at once
+    const float m1 = fmaxf(fmaxf(a.F0.x, a.F0.y), a.F1.x), m2 = fmaxf(fmaxf(a.F1.y, b.F0.x), b.F0.y);
+    const float m = fmaxf(fmaxf(fmaxf(m1, m2), b.F1.x), b.F1.y);
+    if (__ballot(m >= r.thr)) {
+        RT_STAT(7); // groups of eight entered (per wave)
+        push_cand(cq, count, a.F0.x, r.thr, idx, lane);
+        push_cand(cq, count, a.F0.y, r.thr, idx + 1, lane);
+        push_cand(cq, count, a.F1.x, r.thr, idx + 2, lane);
+        push_cand(cq, count, a.F1.y, r.thr, idx + 3, lane);
+        push_cand(cq, count, b.F0.x, r.thr, idx + 4, lane);
+        push_cand(cq, count, b.F0.y, r.thr, idx + 5, lane);
+        push_cand(cq, count, b.F1.x, r.thr, idx + 6, lane);
+        push_cand(cq, count, b.F1.y, r.thr, idx + 7, lane);
+        while (count >= 64) resolve_batch(cq, count, 64, lane, o, dh, tmin, self_id, sph);
     }
 }
 
