@@ -6,12 +6,13 @@ bounce loop -> tone-map; for N > 1 also the RCCL gather of the strips onto rank 
 The scene is already resident in HBM when the timed region starts.
 
 Workloads (the benchmark configurations c2..c5):
-  c3  random-spheres scene (485 spheres), 1200x675, 500 spp, depth 50   [default]
-      with N GPUs the frame grows to 1200 x (675*N) so that every GPU keeps the
-      same amount of work (weak scaling); strips of 8 rows are dealt round-robin.
+  c4  random-spheres scene (485 spheres), 3840x2160, 1000 spp, depth 50   [default, every N]
+      the fixed 4K frame is split over the N GPUs in 8-row strips dealt round-robin
+      (strong scaling): the same configuration at N = 1, 2, 4, 8.
+  c3  random-spheres 1200x675, 500 spp, depth 50; also timed as a secondary figure of the
+      default N = 1 line ("c3" object)
   c2  small scene 1920x1080, 100 spp, depth 50
-  c4  random-spheres 3840x2160, 1000 spp, depth 50 (fixed frame split over the GPUs)
-  c5  10k-sphere grid scene 3840x2160, 256 spp, depth 50 (fixed frame split over the GPUs)
+  c5  10k-sphere grid scene 3840x2160, 256 spp, depth 50
 
 Launch: python bench.py --gpus 1, or under torch.distributed.run for N > 1.
 """
@@ -28,14 +29,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 256 FLOP/clk x 2.4 GHz
-FLOP_PER_TEST = 17        # one ray/sphere test: oc 3, oc.d 5, oc.oc - r^2 6, hb^2 - a*c 3
+FLOP_PER_TEST = 17        # one ray/sphere test as the reference states it: oc 3, oc.d 5, oc.oc - r^2 6, hb^2 - a*c 3
+FLOP_PER_TEST_EXECUTED = 14  # what the kernel issues per test: 7 fused multiply-adds of the packed filter
 FLOP_PER_RAY = 80         # per closest-hit query: d.d, hit point, normal, scatter / sky
 
 WORKLOADS = {
-    "c2": dict(scene="small", width=1920, height=1080, spp=100, depth=50, weak=False),
-    "c3": dict(scene="random_spheres", width=1200, height=675, spp=500, depth=50, weak=True),
-    "c4": dict(scene="random_spheres", width=3840, height=2160, spp=1000, depth=50, weak=False),
-    "c5": dict(scene="grid10k", width=3840, height=2160, spp=256, depth=50, weak=False),
+    "c2": dict(scene="small", width=1920, height=1080, spp=100, depth=50),
+    "c3": dict(scene="random_spheres", width=1200, height=675, spp=500, depth=50),
+    "c4": dict(scene="random_spheres", width=3840, height=2160, spp=1000, depth=50),
+    "c5": dict(scene="grid10k", width=3840, height=2160, spp=256, depth=50),
 }
 
 
@@ -64,25 +66,106 @@ def cpu_baseline(scene, cfg, seconds_target=15.0):
     }
 
 
-def committed_traffic(args, world):
-    """HBM bytes per launch of render_kernel for the default command, from the separate rocprofv3 --pmc
-    passes whose summary is committed under profiles/ (FETCH_SIZE and WRITE_SIZE cannot be read from
-    inside this process).  FETCH_SIZE is doubled as the gfx950 counter tallies 128-byte requests at 64;
-    both counters report KiB.  None for any other workload or GPU count."""
-    if args.workload != "c3" or args.spp or world != 1:
+def committed_traffic(workload, args, world):
+    """HBM bytes per launch of render_kernel for `workload` at one GPU, from the separate rocprofv3
+    --pmc passes whose summaries are committed under profiles/ (FETCH_SIZE and WRITE_SIZE cannot be
+    read from inside this process).  FETCH_SIZE is doubled as the gfx950 counter tallies 128-byte
+    requests at 64; both counters report KiB.  None when no summary of this workload exists."""
+    if args.spp or world != 1:
         return None, None
     here = os.path.dirname(os.path.abspath(__file__))
     rounds = sorted(d for d in os.listdir(os.path.join(here, "profiles")) if d.startswith("r")) \
         if os.path.isdir(os.path.join(here, "profiles")) else []
     for r in reversed(rounds):
-        f = os.path.join(here, "profiles", r, "pmc_summary.json")
+        f = os.path.join(here, "profiles", r, f"{workload}_summary.json")
         if os.path.exists(f):
             try:
                 d = json.load(open(f))
-                return int((2 * d["fetch"]["FETCH_SIZE"] + d["write"]["WRITE_SIZE"]) * 1024), f"profiles/{r}/pmc_summary.json"
+                return int((2 * d["fetch"]["FETCH_SIZE"] + d["write"]["WRITE_SIZE"]) * 1024), f"profiles/{r}/{workload}_summary.json"
             except (KeyError, ValueError):
                 return None, None
     return None, None
+
+
+class Job:
+    """One workload set up on this rank: scene resident, strip buffers and gather ready."""
+
+    def __init__(self, name, args, rank, world, local_rank, dev, with_accum):
+        import torch
+        from raytracer_amd import Renderer, RenderParams, scenes
+        from raytracer_amd.multi_gpu import StripGather
+
+        self.torch = torch
+        self.cfg = dict(WORKLOADS[name])
+        if args.spp:
+            self.cfg["spp"] = args.spp
+        self.name, self.world, self.rank = name, world, rank
+        self.W, self.H = self.cfg["width"], self.cfg["height"]
+        self.scene = scenes.by_name(self.cfg["scene"])
+        self.r = Renderer(local_rank)
+        self.r.set_scene(self.scene)
+        self.p = RenderParams(self.W, self.H, samples_per_pixel=self.cfg["spp"], max_depth=self.cfg["depth"], seed=0,
+                              strip_first=rank, strip_stride=world)
+        self.gather = StripGather(self.W, self.H, rank, world, dev, stage_on_host=(args.backend == "gloo"))
+        self.rgba = self.gather.local_buffer()
+        self.accum = torch.zeros((self.rgba.shape[0], self.W, 4), dtype=torch.float32, device=dev) if with_accum else None
+        self.rays = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def step(self, seed, ev=None):
+        self.p.seed = seed
+        if ev:
+            ev[0].record()
+        self.r.render_device(self.p, self.rgba, self.accum, self.rays, self.stream)
+        if ev:
+            ev[1].record()
+        frame = self.gather.gather(self.rgba)  # rank 0: the assembled H x W x 4 frame
+        if ev:
+            ev[2].record()
+        return frame
+
+    def run(self, steps, warmup, sync):
+        """-> (wall seconds of `steps` steps, mean kernel ms, mean gather ms, rays of this rank)"""
+        torch = self.torch
+        for i in range(warmup):
+            self.step(1000 + i)
+        self.rays.zero_()
+        ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(steps)]
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(i, ev[i])
+        sync()
+        dt = time.perf_counter() - t0
+        kern = sum(a.elapsed_time(b) for a, b, _ in ev) / steps
+        gath = sum(b.elapsed_time(c) for _, b, c in ev) / steps
+        return dt, kern, gath, int(self.rays.item())
+
+    def roofline(self, kern_ms, rays_per_launch, args):
+        n_s = self.scene.n_spheres
+        achieved = rays_per_launch * (FLOP_PER_TEST * n_s + FLOP_PER_RAY) / (kern_ms * 1e-3) / 1e12
+        executed = rays_per_launch * (FLOP_PER_TEST_EXECUTED * n_s + FLOP_PER_RAY) / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = committed_traffic(self.name, args, self.world)
+        return {
+            "bound": "valu_fp32",
+            "achieved": round(achieved, 3),
+            "peak": PEAK_FP32_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+            # the same launch priced at the 14 FLOP per test the packed filter really issues
+            "executed_frac": round(executed / PEAK_FP32_TFLOPS, 4),
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "kernel": "render_kernel",
+            "kernel_ms": round(kern_ms, 3),
+            "flop_model": f"algorithmic rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}); executed "
+                          f"rays*({FLOP_PER_TEST_EXECUTED}*{n_s}+{FLOP_PER_RAY}); rays/launch={rays_per_launch:.0f}",
+        }
+
+    def describe(self):
+        c = self.cfg
+        return (f"{self.name}: {c['scene']} scene ({self.scene.n_spheres} spheres) {self.W}x{self.H}, {c['spp']} spp, "
+                f"depth {c['depth']}, samplesPerScatter 1, no lights")
 
 
 def main():
@@ -90,9 +173,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline)")
+    ap.add_argument("--accum", action="store_true", help="also write the 16 B/px radiance sums")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the c3 figure of the default N = 1 line")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearse the N > 1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
@@ -100,9 +185,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-
-    from raytracer_amd import Renderer, RenderParams, scenes
-    from raytracer_amd.multi_gpu import StripGather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,69 +206,28 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    cfg = dict(WORKLOADS[args.workload])
-    if args.spp:
-        cfg["spp"] = args.spp
-    W = cfg["width"]
-    H = cfg["height"] * (world if cfg["weak"] else 1)
-    scene = scenes.by_name(cfg["scene"])
-
-    r = Renderer(local_rank)
-    r.set_scene(scene)
-    p = RenderParams(W, H, samples_per_pixel=cfg["spp"], max_depth=cfg["depth"], seed=0,
-                     strip_first=rank, strip_stride=world)
-    gather = StripGather(W, H, rank, world, dev, stage_on_host=(args.backend == "gloo"))
-    rgba = gather.local_buffer()
-    accum = torch.zeros((rgba.shape[0], W, 4), dtype=torch.float32, device=dev)
-    rays = torch.zeros(1, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step(seed):
-        p.seed = seed
-        r.render_device(p, rgba, accum, rays, stream)
-        return gather.gather(rgba)  # rank 0: the assembled H x W x 4 frame
-
-    for i in range(args.warmup):
-        step(1000 + i)
-    rays.zero_()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        p.seed = i
-        ev[i][0].record()
-        r.render_device(p, rgba, accum, rays, stream)
-        ev[i][1].record()
-        frame = gather.gather(rgba)
-    sync()
-    dt = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    job = Job(args.workload, args, rank, world, local_rank, dev, args.accum)
+    dt, kern_ms, gather_ms, my_rays = job.run(args.steps, args.warmup, sync)
 
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
-    t = torch.tensor([dt, sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device=red_dev)
-    rays_total = rays.clone().to(red_dev)
+    hi = torch.tensor([dt, kern_ms, gather_ms], dtype=torch.float64, device=red_dev)
+    lo = torch.tensor([kern_ms, gather_ms], dtype=torch.float64, device=red_dev)
+    rays_total = torch.tensor([my_rays], dtype=torch.int64, device=red_dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)
-    dt = float(t[0])
-    kern_ms = float(t[1])
-    my_rays = int(rays.item())
+    dt = float(hi[0])
 
     if rank == 0:
-        samples = W * H * cfg["spp"] * args.steps
-        n_s = scene.n_spheres
-        # dominant kernel: render_kernel on this rank; algorithmic FLOPs of one launch / its duration
-        rays_per_launch = my_rays / args.steps
-        flops = rays_per_launch * (FLOP_PER_TEST * n_s + FLOP_PER_RAY)
-        achieved = flops / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_src = committed_traffic(args, world)
+        cfg = job.cfg
+        samples = job.W * job.H * cfg["spp"] * args.steps
         out = {
             "metric": "Msamples/sec (px*spp, depth<=50)",
             "value": round(samples / dt / 1e6, 3),
@@ -196,31 +237,37 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak" if cfg["weak"] else "strong",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {cfg['scene']} scene ({n_s} spheres) {W}x{H}, {cfg['spp']} spp, "
-                            f"depth {cfg['depth']}, samplesPerScatter 1, no lights",
+                "workload": job.describe(),
                 "parallelism": f"{world} GPU(s), 8-row strips round-robin, RGBA8 gather to rank 0",
                 "rays_per_sample": round(int(rays_total.item()) / samples, 4),
             },
-            "roofline": {
-                "bound": "valu_fp32",
-                "achieved": round(achieved, 3),
-                "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "kernel": "render_kernel",
-                "kernel_ms": round(kern_ms, 3),
-                "flop_model": f"rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}), rays/launch={rays_per_launch:.0f}",
+            # per-rank means over the timed steps: the spread of kernel_ms is the load balance of the
+            # strip deal, gather_ms the cost of assembling the frame on rank 0
+            "per_rank": {
+                "kernel_ms_min": round(float(lo[0]), 3), "kernel_ms_max": round(float(hi[1]), 3),
+                "gather_ms_min": round(float(lo[1]), 3), "gather_ms_max": round(float(hi[2]), 3),
             },
+            # dominant kernel: render_kernel on this rank; algorithmic FLOPs of one launch / its duration
+            "roofline": job.roofline(kern_ms, my_rays / args.steps, args),
         }
+        if world == 1 and args.workload == "c4" and not args.spp and not args.no_secondary:
+            sec = Job("c3", args, rank, world, local_rank, dev, args.accum)
+            sdt, skern, _, srays = sec.run(max(args.steps, 5), 1, sync)
+            n = max(args.steps, 5)
+            out["c3"] = {
+                "workload": sec.describe(),
+                "value": round(sec.W * sec.H * sec.cfg["spp"] * n / sdt / 1e6, 3),
+                "unit": "Msamples/s",
+                "ms_per_step": round(sdt / n * 1e3, 3),
+                "roofline": sec.roofline(skern, srays / n, args),
+            }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cfg)
+            out["cpu_baseline"] = cpu_baseline(job.scene, cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -2,7 +2,7 @@
 # usage: tools/pmc.sh <tag> <counters...>   -- one rocprofv3 --pmc pass over a 1-step bench run
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$tag.log 2>&1
+timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --workload c3 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$tag.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 agg=collections.defaultdict(float); n=0
