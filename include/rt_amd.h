@@ -12,7 +12,8 @@
  *   - every function returns 0 on success, a negative rt_status otherwise, and
  *     never throws; rt_last_error() gives a printable reason.  (The reference
  *     uses assert()/silent clamps only, src/Camera.cpp:76-77.)
- *   - one context per device; a context is not re-entrant.
+ *   - one context per device; a context is not re-entrant (calls on one context come from one
+ *     host thread at a time; up to 16 asynchronous renders may be in flight on its streams).
  *   - plain pointers and sizes only; "d_" arguments are DEVICE pointers valid on
  *     the context's device, "h_" arguments are HOST pointers.
  *   - the library never falls back to a CPU renderer: scenes it cannot render
@@ -196,6 +197,19 @@ int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
  */
 int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum,
               uint64_t *d_rays, void *stream);
+
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the same render as
+ * rt_render() with the kernel's work counter taken from a device array of the library's code object
+ * (RT_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends) instead of the context's
+ * allocation.  The call itself allocates and frees nothing; scene, camera and the output buffers
+ * are the caller's and the context's, set up beforehand as for rt_render().
+ * Limits: at most 2^31 - 1 work items per call (width*height < 2^31), rejected with RT_ERR_INVALID
+ * beyond that.  All contexts on one GPU share the array's 16 counters, used round robin: up to 16
+ * calls may be in flight on one GPU, more than that race. */
+#define RT_NOALLOC_SCRATCH_BYTES 4096
+int rt_render_noalloc(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum,
+                      uint64_t *d_rays, void *stream);
 
 /* Same, with HOST outputs and a synchronous copy-out: this is the function a
  * Camera::render binding calls with outputBufer.data().  h_rays receives (is

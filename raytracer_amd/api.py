@@ -78,7 +78,8 @@ class RenderParams:
 
 EXPORTS = [
     "rt_version", "rt_rng4", "rt_output_rows", "rt_create", "rt_destroy", "rt_last_error",
-    "rt_upload_scene", "rt_upload_scene_ex", "rt_upload_lights", "rt_set_camera", "rt_render", "rt_render_host",
+    "rt_upload_scene", "rt_upload_scene_ex", "rt_upload_lights", "rt_set_camera", "rt_render", "rt_render_noalloc",
+    "rt_render_host",
     "rt_first_hit", "rt_first_hit_host", "rt_first_hit_ex", "rt_first_hit_ex_host", "rt_scatter_host",
 ]
 
@@ -118,6 +119,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rt_set_camera.restype = C.c_int
     lib.rt_render.argtypes = [vp, C.POINTER(_Params), vp, vp, vp, vp]
     lib.rt_render.restype = C.c_int
+    lib.rt_render_noalloc.argtypes = [vp, C.POINTER(_Params), vp, vp, vp, vp]
+    lib.rt_render_noalloc.restype = C.c_int
     lib.rt_render_host.argtypes = [vp, C.POINTER(_Params), vp, vp, C.POINTER(C.c_uint64)]
     lib.rt_render_host.restype = C.c_int
     lib.rt_first_hit.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp]
@@ -249,14 +252,15 @@ class Renderer:
         )
         return rgba, accum, int(rays.value)
 
-    def render_device(self, p: RenderParams, rgba, accum=None, rays=None, stream=None):
+    def render_device(self, p: RenderParams, rgba, accum=None, rays=None, stream=None, noalloc: bool = False):
         """Asynchronous render into torch CUDA tensors (device pointers).
 
-        rgba: uint8 [rows, W, 4]; accum: float32 [rows, W, 4] or None; rays: int64 [1] or None."""
+        rgba: uint8 [rows, W, 4]; accum: float32 [rows, W, 4] or None; rays: int64 [1] or None.
+        noalloc: go through rt_render_noalloc (work counter in the library's static device array)."""
         cp = p.to_c()
         st = C.c_void_p(stream) if stream else None
         self._check(
-            self.lib.rt_render(
+            (self.lib.rt_render_noalloc if noalloc else self.lib.rt_render)(
                 self.h, C.byref(cp), C.c_void_p(rgba.data_ptr()),
                 C.c_void_p(accum.data_ptr()) if accum is not None else None,
                 C.c_void_p(rays.data_ptr()) if rays is not None else None, st,

@@ -20,6 +20,8 @@
 #include <vector>
 #include <new>
 #include <cmath>
+#include <atomic>
+#include <mutex>
 
 #include "../../include/rt_amd.h"
 #include "rt_device.h"
@@ -1004,6 +1006,44 @@ __global__ void scatter_kernel(int n, const DMat *__restrict__ mats, const uint3
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+
+// The persistent render kernel pulls its work items from a 32-bit counter in device memory.  A launch
+// takes the next of QUEUE_SLOTS counters (256 bytes apart), so renders issued back to back on
+// different streams do not share one.
+constexpr int QUEUE_SLOTS = 16;
+constexpr size_t QUEUE_SLOT_BYTES = 256;
+
+// Counters of rt_render_noalloc: a device array of the code object instead of a hipMalloc'ed buffer.
+// Every GPU holds its own copy at its own address; `scratch` itself is only a host-side handle, the
+// device address comes from hipGetSymbolAddress (scratch_ptr below) and is what kernels and
+// hipMemsetAsync receive.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+static_assert(RT_NOALLOC_SCRATCH_BYTES == QUEUE_SLOTS * QUEUE_SLOT_BYTES, "scratch holds one ring of work counters");
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[MAX_DEVICES]; // per device: address of its copy of `scratch`, null until looked up
+std::atomic<unsigned> g_scratch_next[MAX_DEVICES];
+
+// Address of `scratch` on `device`, looked up once per device with that device current.
+hipError_t scratch_ptr(int device, unsigned char **out) {
+    *out = nullptr;
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return e;
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+} // namespace
+
 struct rt_ctx {
     int device = 0;
     std::string err;
@@ -1012,7 +1052,9 @@ struct rt_ctx {
     float4 *d_r2q = nullptr;
     int n_quads = 0;
     bool scalar_source = true;
-    unsigned *d_queue = nullptr; // work-item counter of the persistent render kernel (256 B, zeroed per launch)
+    unsigned char *d_queue = nullptr; // ring of work-item counters of the persistent render kernel
+    unsigned queue_next = 0;          // next slot of the ring
+    unsigned char *d_scratch = nullptr; // this device's copy of `scratch` (rt_render_noalloc)
     int n_cus = 256;
     int wgs_per_cu = 8;
     int force_tile = -1; // tuning: 0 = 1x1, 1 = 2x2, 2 = 4x4, 3 = 8x8 work-item tiles
@@ -1146,7 +1188,9 @@ RT_API int rt_create(int device, rt_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cus = prop.multiProcessorCount;
-    if (hipMalloc((void **)&ctx->d_queue, 256) != hipSuccess) {
+    if (hipMalloc((void **)&ctx->d_queue, QUEUE_SLOTS * QUEUE_SLOT_BYTES) != hipSuccess ||
+        scratch_ptr(device, &ctx->d_scratch) != hipSuccess) {
+        if (ctx->d_queue) (void)hipFree(ctx->d_queue);
         delete ctx;
         return RT_ERR_HIP;
     }
@@ -1366,8 +1410,10 @@ RT_API int rt_set_camera(rt_ctx *ctx, const rt_camera *cam) {
     return RT_OK;
 }
 
-RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, uint64_t *d_rays,
-                     void *stream) {
+namespace {
+// Launches the render kernel of `p` with `queue` (device memory, 256 bytes) as its work counter.
+int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, uint64_t *d_rays, void *stream,
+                unsigned *queue) {
     int rc = check_params(ctx, p);
     if (rc != RT_OK) return rc;
     if (!d_rgba) return fail(ctx, RT_ERR_INVALID, "d_rgba is null");
@@ -1426,7 +1472,7 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
     uchar4 *o_rgba = (uchar4 *)d_rgba;
     float4 *o_acc = (float4 *)d_accum;
     unsigned long long *o_rays = (unsigned long long *)d_rays;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 256, st));
+    HIP_TRY(ctx, hipMemsetAsync(queue, 0, QUEUE_SLOT_BYTES, st));
     // the general kernel serves lights, the non-sphere primitives and the selection halo
     const bool full = k.n_lights > 0 || ctx->n_others > 0 || ctx->n_halo > 0;
     size_t lds = WAVE_STATE_BYTES;
@@ -1440,13 +1486,33 @@ RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accu
         lds += (size_t)(resident ? (ctx->n_quads > 0 ? ctx->n_quads : 1) : STREAM_QUADS) * 5 * sizeof(float4);
     }
 #define RT_LAUNCH(S, L)                                                                                   \
-    hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays, ctx->d_queue)
+    hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays, queue)
     if (src == SRC_SCALAR) RT_LAUNCH(SRC_SCALAR, false);
     else if (src == SRC_LDS_RESIDENT) { if (full) RT_LAUNCH(SRC_LDS_RESIDENT, true); else RT_LAUNCH(SRC_LDS_RESIDENT, false); }
     else { if (full) RT_LAUNCH(SRC_LDS_STREAMED, true); else RT_LAUNCH(SRC_LDS_STREAMED, false); }
 #undef RT_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
+}
+} // namespace
+
+RT_API int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, uint64_t *d_rays,
+                     void *stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    unsigned char *slot = ctx->d_queue + (size_t)(ctx->queue_next++ % QUEUE_SLOTS) * QUEUE_SLOT_BYTES;
+    return render_impl(ctx, p, d_rgba, d_accum, d_rays, stream, reinterpret_cast<unsigned *>(slot));
+}
+
+RT_API int rt_render_noalloc(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, uint64_t *d_rays,
+                             void *stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->d_scratch) return fail(ctx, RT_ERR_STATE, "rt_render_noalloc: the device's scratch array was not found");
+    // the counter is 32 bits wide: a call may cover at most 2^31 - 1 work items (tiles of 1 to 64 pixels)
+    if (p && p->width > 0 && p->height > 0 && (long long)p->width * (long long)p->height > 0x7fffffffLL)
+        return fail(ctx, RT_ERR_INVALID, "rt_render_noalloc: more work items than the 32-bit counter in scratch holds");
+    const unsigned n = g_scratch_next[ctx->device].fetch_add(1u);
+    unsigned char *slot = ctx->d_scratch + (size_t)(n % QUEUE_SLOTS) * QUEUE_SLOT_BYTES;
+    return render_impl(ctx, p, d_rgba, d_accum, d_rays, stream, reinterpret_cast<unsigned *>(slot));
 }
 
 RT_API int rt_render_host(rt_ctx *ctx, const rt_params *p, uint8_t *h_rgba, float *h_accum, uint64_t *h_rays) {

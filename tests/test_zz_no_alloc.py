@@ -1,0 +1,90 @@
+"""rt_render_noalloc (work counter in the library's static device array) against rt_render, through
+the C ABI: byte-identical frames, radiance sums and ray counts on two calls in a row, the second with
+a smaller input.  The entry point has no counterpart in the reference; bar: bit-exact (integer/byte
+outputs of the same kernel)."""
+import numpy as np
+import pytest
+
+from raytracer_amd import Renderer, RenderParams, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+class _DevBuf:
+    """A device buffer from the HIP runtime the library itself loaded (no torch in this test: importing
+    it after the library would bring a second HIP runtime into the process)."""
+
+    def __init__(self, hip, nbytes):
+        import ctypes as C
+
+        self.hip, self.nbytes, self.ptr = hip, nbytes, C.c_void_p()
+        assert hip.hipMalloc(C.byref(self.ptr), C.c_size_t(nbytes)) == 0
+        assert hip.hipMemset(self.ptr, 0, C.c_size_t(nbytes)) == 0
+
+    def data_ptr(self):
+        return self.ptr.value
+
+    def to_numpy(self, dtype, shape):
+        import ctypes as C
+
+        out = np.zeros(shape, dtype=dtype)
+        assert out.nbytes == self.nbytes
+        assert self.hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, C.c_size_t(self.nbytes), 2) == 0  # D2H
+        return out
+
+    def free(self):
+        self.hip.hipFree(self.ptr)
+
+
+def _render(r, p, noalloc):
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")  # already in the process: the library links against it
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    n = p.width * p.height
+    rgba, accum, rays = _DevBuf(hip, n * 4), _DevBuf(hip, n * 16), _DevBuf(hip, 8)
+    r.render_device(p, rgba, accum, rays, None, noalloc=noalloc)
+    assert hip.hipDeviceSynchronize() == 0
+    out = (rgba.to_numpy(np.uint8, (p.height, p.width, 4)), accum.to_numpy(np.float32, (p.height, p.width, 4)),
+           int(rays.to_numpy(np.int64, (1,))[0]))
+    for b in (rgba, accum, rays):
+        b.free()
+    return out
+
+
+CASES = [("random_spheres", 200, 120, 24, 50), ("small_bubble", 96, 54, 16, 10)]  # the second is the smaller input
+
+
+def test_noalloc_matches_render_on_two_calls_in_a_row():
+    with Renderer(0) as r:
+        def run(noalloc):
+            out = []
+            for name, W, H, spp, depth in CASES:
+                r.set_scene(scenes.by_name(name))
+                out.append(_render(r, RenderParams(W, H, samples_per_pixel=spp, max_depth=depth, seed=7), noalloc))
+            return out
+
+        got = run(noalloc=True)  # two calls of the new entry point in a row
+        want = run(noalloc=False)
+        for (name, *_), g, w in zip(CASES, got, want):
+            assert np.array_equal(g[0], w[0]), f"{name}: RGBA8 frames differ"
+            assert np.array_equal(g[1], w[1]), f"{name}: radiance sums differ"
+            assert g[2] == w[2] and g[2] > 0
+            assert g[0][..., :3].any(), "frame is black"
+
+
+def test_noalloc_rejects_what_it_cannot_count():
+    from raytracer_amd import RtError
+
+    with Renderer(0) as r:
+        r.set_scene(scenes.small_scene())
+        class Fake:
+            def data_ptr(self):
+                return 256  # never dereferenced: the call is refused before any launch
+
+        with pytest.raises(RtError):
+            # 65536 x 65536 pixels: more work items than the 32-bit counter holds
+            r.render_device(RenderParams(65536, 65536, 1, 1), Fake(), None, None, None, noalloc=True)
