@@ -217,6 +217,14 @@ int rt_render_noalloc(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_acc
 int rt_render_host(rt_ctx *ctx, const rt_params *p, uint8_t *h_rgba, float *h_accum,
                    uint64_t *h_rays);
 
+/* Duration in milliseconds of the render kernel of the last rt_render_host() call (HIP events on the
+ * context's stream), and the number of device allocations (hipMalloc calls) made for the context so
+ * far: its buffers are kept and only grown, so a second frame of an unchanged scene adds none.
+ * Replaces nothing in the reference; for callers that drive the camera per frame
+ * (Camera::move / rotate then render, reference src/Camera.cpp:43-67). */
+float rt_last_kernel_ms(const rt_ctx *ctx);
+uint64_t rt_device_allocations(const rt_ctx *ctx);
+
 /* First-hit flags */
 enum {
     RT_FH_REFINE = 1u << 0,  /* re-test numerically ambiguous rays in fp64 so that the
@@ -261,6 +269,43 @@ int rt_scatter_host(rt_ctx *ctx, int n, const uint32_t *h_mat, const float *h_in
                     const float *h_point, const float *h_normal, const uint8_t *h_front,
                     const float *h_u, float *h_att, float *h_out_org, float *h_out_dir,
                     uint8_t *h_scattered_flag);
+
+/* ---- device groups: one frame on several GPUs of one process ---------------------------------
+ * Replaces the OpenMP team of Camera::renderParallel (reference src/Camera.cpp:69-88: pixels are
+ * independent and each is seeded by its own id) by a team of GPUs: member i of n renders the 8-row
+ * strips i, i+n, ... on its own stream, the strips are gathered on the first member's GPU (RCCL
+ * send/recv over xGMI between distinct GPUs, device copies when a GPU is listed more than once)
+ * and dealt back into row order there.  The frame equals the one-GPU frame byte for byte.
+ * A group owns one context per list entry; scene, lights and camera are replicated to all. */
+typedef struct rt_group rt_group;
+
+typedef struct rt_group_timing {
+    float kernel_ms_min; /* shortest and longest render kernel over the members (HIP events)  */
+    float kernel_ms_max;
+    float gather_ms;     /* total_ms - kernel_ms_max: launches, exchange, assembly, copy-out   */
+    float total_ms;      /* host wall time of the call                                          */
+} rt_group_timing;
+
+int rt_group_create(int n_members, const int *devices, rt_group **out);
+void rt_group_destroy(rt_group *g);
+const char *rt_group_last_error(const rt_group *g);
+int rt_group_size(const rt_group *g);
+const char *rt_group_transport(const rt_group *g); /* "rccl", "copy" or "rccl-loopback" */
+uint64_t rt_group_device_allocations(const rt_group *g);
+int rt_group_upload_scene_ex(rt_group *g, int n_prims, const rt_prim *h_prims, int n_vertices,
+                             const float *h_vertices, int n_mats, const rt_material *h_mats);
+int rt_group_upload_lights(rt_group *g, int n_lights, const rt_light *h_lights);
+int rt_group_set_camera(rt_group *g, const rt_camera *cam);
+/* p->strip_first / strip_stride must be 0 / 1 (the group deals the strips).  *d_frame receives the
+ * assembled frame in the first member's device memory (height rounded up to whole strips, valid
+ * until the next call); h_rays the closest-hit queries of all members; timing may be NULL.
+ * Synchronous. */
+int rt_group_render(rt_group *g, const rt_params *p, void **d_frame, uint64_t *h_rays,
+                    rt_group_timing *timing);
+/* Same with the width*height*4 bytes of the frame copied to host memory: what a multi-GPU
+ * Camera::render binding calls with outputBufer.data(). */
+int rt_group_render_host(rt_group *g, const rt_params *p, uint8_t *h_rgba, uint64_t *h_rays,
+                         rt_group_timing *timing);
 
 /* The counter-based generator the kernels use, exposed for tests:
  * fills out[4] with the four 32-bit words of stream (pixel, sample, call, seed). */

@@ -5,7 +5,7 @@ The product is the C-ABI shared library built from ``csrc/rt_amd.hip`` (declared
 binding (``api``), the build-defined benchmark scenes (``scenes``) and the
 multi-GPU strip partition + gather (``multi_gpu``).
 """
-from .api import Renderer, RtError, load_library, RenderParams  # noqa: F401
+from .api import Group, Renderer, RtError, load_library, RenderParams  # noqa: F401
 from . import scenes  # noqa: F401
 
-__all__ = ["Renderer", "RtError", "load_library", "RenderParams", "scenes"]
+__all__ = ["Group", "Renderer", "RtError", "load_library", "RenderParams", "scenes"]

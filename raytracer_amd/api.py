@@ -55,6 +55,11 @@ class _Params(C.Structure):
     ]
 
 
+class _GroupTiming(C.Structure):
+    _fields_ = [("kernel_ms_min", C.c_float), ("kernel_ms_max", C.c_float), ("gather_ms", C.c_float),
+                ("total_ms", C.c_float)]
+
+
 @dataclass
 class RenderParams:
     """CameraRenderProperties (reference inc/Camera.h:14-22) + frame geometry + strip partition."""
@@ -79,7 +84,10 @@ class RenderParams:
 EXPORTS = [
     "rt_version", "rt_rng4", "rt_output_rows", "rt_create", "rt_destroy", "rt_last_error",
     "rt_upload_scene", "rt_upload_scene_ex", "rt_upload_lights", "rt_set_camera", "rt_render", "rt_render_noalloc",
-    "rt_render_host",
+    "rt_render_host", "rt_last_kernel_ms", "rt_device_allocations",
+    "rt_group_create", "rt_group_destroy", "rt_group_last_error", "rt_group_size", "rt_group_transport",
+    "rt_group_device_allocations", "rt_group_upload_scene_ex", "rt_group_upload_lights", "rt_group_set_camera",
+    "rt_group_render", "rt_group_render_host",
     "rt_first_hit", "rt_first_hit_host", "rt_first_hit_ex", "rt_first_hit_ex_host", "rt_scatter_host",
 ]
 
@@ -123,6 +131,32 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rt_render_noalloc.restype = C.c_int
     lib.rt_render_host.argtypes = [vp, C.POINTER(_Params), vp, vp, C.POINTER(C.c_uint64)]
     lib.rt_render_host.restype = C.c_int
+    lib.rt_last_kernel_ms.argtypes = [vp]
+    lib.rt_last_kernel_ms.restype = C.c_float
+    lib.rt_device_allocations.argtypes = [vp]
+    lib.rt_device_allocations.restype = C.c_uint64
+    lib.rt_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+    lib.rt_group_create.restype = C.c_int
+    lib.rt_group_destroy.argtypes = [vp]
+    lib.rt_group_destroy.restype = None
+    lib.rt_group_last_error.argtypes = [vp]
+    lib.rt_group_last_error.restype = C.c_char_p
+    lib.rt_group_size.argtypes = [vp]
+    lib.rt_group_size.restype = C.c_int
+    lib.rt_group_transport.argtypes = [vp]
+    lib.rt_group_transport.restype = C.c_char_p
+    lib.rt_group_device_allocations.argtypes = [vp]
+    lib.rt_group_device_allocations.restype = C.c_uint64
+    lib.rt_group_upload_scene_ex.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
+    lib.rt_group_upload_scene_ex.restype = C.c_int
+    lib.rt_group_upload_lights.argtypes = [vp, C.c_int, vp]
+    lib.rt_group_upload_lights.restype = C.c_int
+    lib.rt_group_set_camera.argtypes = [vp, vp]
+    lib.rt_group_set_camera.restype = C.c_int
+    lib.rt_group_render.argtypes = [vp, C.POINTER(_Params), C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(_GroupTiming)]
+    lib.rt_group_render.restype = C.c_int
+    lib.rt_group_render_host.argtypes = [vp, C.POINTER(_Params), vp, C.POINTER(C.c_uint64), C.POINTER(_GroupTiming)]
+    lib.rt_group_render_host.restype = C.c_int
     lib.rt_first_hit.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp]
     lib.rt_first_hit.restype = C.c_int
     lib.rt_first_hit_host.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp]
@@ -268,6 +302,12 @@ class Renderer:
             "rt_render",
         )
 
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.rt_last_kernel_ms(self.h))
+
+    def device_allocations(self) -> int:
+        return int(self.lib.rt_device_allocations(self.h))
+
     # -- first hit / scatter --------------------------------------------------
     def first_hit(self, org: np.ndarray, dir: np.ndarray, tmin: float = 0.001, refine: bool = False,
                   expanded_state: bool = False, want_expanded: bool = False):
@@ -312,3 +352,81 @@ class Renderer:
             "rt_scatter_host",
         )
         return att, oo, od, flag
+
+
+class Group:
+    """Several GPUs of this process rendering one frame (rt_group): member i renders strips i, i+n, ...;
+    the strips are gathered on the first member's GPU.  A device may be listed more than once."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.lib.rt_group_create(len(devices), arr, C.byref(h))
+        if rc != 0 or not h:
+            raise RtError(f"rt_group_create({list(devices)}) failed with status {rc}")
+        self.h = h
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.rt_group_last_error(self.h)
+            raise RtError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    @property
+    def transport(self) -> str:
+        return self.lib.rt_group_transport(self.h).decode()
+
+    def device_allocations(self) -> int:
+        return int(self.lib.rt_group_device_allocations(self.h))
+
+    def set_scene(self, scene):
+        if getattr(scene, "needs_general", False):
+            prims, verts = scene.prims, scene.verts
+        else:
+            prims = np.zeros(len(scene.spheres), dtype=PRIM_DTYPE)
+            prims["type"] = PRIM_SPHERE
+            prims["mat"] = scene.mat_id
+            for k, f in enumerate(("cx", "cy", "cz", "r")):
+                prims["p"][:, k] = scene.spheres[f]
+            verts = None
+        prims = np.ascontiguousarray(prims, dtype=PRIM_DTYPE)
+        mats = np.ascontiguousarray(scene.mats, dtype=MATERIAL_DTYPE)
+        nv = 0 if verts is None else len(verts)
+        v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3) if nv else None
+        self._check(self.lib.rt_group_upload_scene_ex(self.h, len(prims), _ptr(prims) if len(prims) else None, nv,
+                                                      _ptr(v) if nv else None, len(mats), _ptr(mats)),
+                    "rt_group_upload_scene_ex")
+        lights = getattr(scene, "lights", None)
+        n = 0 if lights is None else len(lights)
+        arr = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE) if n else None
+        self._check(self.lib.rt_group_upload_lights(self.h, n, _ptr(arr) if n else None), "rt_group_upload_lights")
+        cam = np.ascontiguousarray(scene.camera, dtype=CAMERA_DTYPE).reshape(1)
+        self._check(self.lib.rt_group_set_camera(self.h, _ptr(cam)), "rt_group_set_camera")
+
+    def render_host(self, p: RenderParams):
+        """-> (rgba[H,W,4] u8, rays, timing dict)"""
+        rgba = np.zeros((p.height, p.width, 4), dtype=np.uint8)
+        rays = C.c_uint64(0)
+        t = _GroupTiming()
+        cp = p.to_c()
+        self._check(self.lib.rt_group_render_host(self.h, C.byref(cp), _ptr(rgba), C.byref(rays), C.byref(t)),
+                    "rt_group_render_host")
+        return rgba, int(rays.value), {f: getattr(t, f) for f, _ in _GroupTiming._fields_}

@@ -21,6 +21,7 @@
 #include <new>
 #include <cmath>
 #include <atomic>
+#include <map>
 #include <mutex>
 
 #include "../../include/rt_amd.h"
@@ -1072,6 +1073,19 @@ struct rt_ctx {
     bool have_scene = false;
     bool have_camera = false;
     rt_camera cam{};
+    // Device buffers are kept and only ever grown: re-uploading a scene of the same size and
+    // rendering a frame of the same size again allocates nothing.
+    std::map<void **, size_t> capacity; // bytes behind each pointer field above and below
+    uint64_t n_allocs = 0;              // hipMalloc calls made for this context
+    // rt_render_host's own stream, outputs and timing
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    float last_kernel_ms = 0.f;
+    void *frame_rgba = nullptr, *frame_accum = nullptr;
+    uint64_t *frame_rays = nullptr;
+    // rt_first_hit_ex_host's staging buffers
+    void *fh_org = nullptr, *fh_dir = nullptr, *fh_id = nullptr, *fh_t = nullptr, *fh_nrm = nullptr, *fh_front = nullptr,
+         *fh_exp = nullptr;
 };
 
 namespace {
@@ -1088,24 +1102,29 @@ int fail(rt_ctx *ctx, int code, const std::string &msg) {
             return fail(ctx, RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
-void free_scene(rt_ctx *ctx) {
-    if (ctx->d_sph) (void)hipFree(ctx->d_sph);
-    if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
-    if (ctx->d_r2q) (void)hipFree(ctx->d_r2q);
-    if (ctx->d_mat_id) (void)hipFree(ctx->d_mat_id);
-    if (ctx->d_mats) (void)hipFree(ctx->d_mats);
-    if (ctx->d_prims) (void)hipFree(ctx->d_prims);
-    if (ctx->d_verts) (void)hipFree(ctx->d_verts);
-    if (ctx->d_others) (void)hipFree(ctx->d_others);
-    if (ctx->d_halo) (void)hipFree(ctx->d_halo);
-    if (ctx->d_sph_gid) (void)hipFree(ctx->d_sph_gid);
-    ctx->d_prims = nullptr;
-    ctx->d_verts = nullptr;
-    ctx->d_others = ctx->d_halo = ctx->d_sph_gid = nullptr;
-    ctx->n_prims = ctx->n_others = ctx->n_halo = 0;
-    ctx->d_sph = ctx->d_pairs = ctx->d_r2q = nullptr;
-    ctx->d_mat_id = nullptr;
-    ctx->d_mats = nullptr;
+// Makes *field point at >= bytes of device memory on the context's device (which must be current),
+// keeping the allocation it has when that is large enough.
+hipError_t reserve(rt_ctx *ctx, void **field, size_t bytes) {
+    if (bytes == 0) bytes = 16; // kernels always get valid pointers
+    size_t &cap = ctx->capacity[field];
+    if (*field && cap >= bytes) return hipSuccess;
+    if (*field) (void)hipFree(*field);
+    *field = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(field, bytes);
+    if (e != hipSuccess) return e;
+    ctx->n_allocs++;
+    cap = bytes;
+    return hipSuccess;
+}
+
+void free_all(rt_ctx *ctx) {
+    for (auto &kv : ctx->capacity)
+        if (*kv.first) {
+            (void)hipFree(*kv.first);
+            *kv.first = nullptr;
+        }
+    ctx->capacity.clear();
     ctx->have_scene = false;
 }
 
@@ -1188,10 +1207,12 @@ RT_API int rt_create(int device, rt_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cus = prop.multiProcessorCount;
-    if (hipMalloc((void **)&ctx->d_queue, QUEUE_SLOTS * QUEUE_SLOT_BYTES) != hipSuccess ||
-        scratch_ptr(device, &ctx->d_scratch) != hipSuccess) {
-        if (ctx->d_queue) (void)hipFree(ctx->d_queue);
-        delete ctx;
+    if (scratch_ptr(device, &ctx->d_scratch) != hipSuccess ||
+        reserve(ctx, (void **)&ctx->d_queue, QUEUE_SLOTS * QUEUE_SLOT_BYTES) != hipSuccess ||
+        reserve(ctx, (void **)&ctx->frame_rays, 8) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        rt_destroy(ctx);
         return RT_ERR_HIP;
     }
     if (const char *w = getenv("RT_AMD_WGS_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 64) ctx->wgs_per_cu = v; }
@@ -1207,9 +1228,11 @@ RT_API int rt_create(int device, rt_ctx **out) {
 RT_API void rt_destroy(rt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    free_scene(ctx);
-    if (ctx->d_lights) (void)hipFree(ctx->d_lights);
-    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -1237,9 +1260,7 @@ DeviceScene device_scene(const rt_ctx *ctx) {
 
 template <typename T>
 int to_device(rt_ctx *ctx, T **dst, const std::vector<T> &src) {
-    // keep at least one element allocated so kernels always get valid pointers
-    size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
-    HIP_TRY(ctx, hipMalloc((void **)dst, bytes));
+    HIP_TRY(ctx, reserve(ctx, (void **)dst, src.size() * sizeof(T)));
     if (!src.empty()) HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return RT_OK;
 }
@@ -1261,7 +1282,9 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
     for (int i = 0; i < n_mats; ++i)
         if (h_mats[i].type > RT_MAT_EMISSIVE) return fail(ctx, RT_ERR_UNSUPPORTED, "unknown material type");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    free_scene(ctx);
+    // a render still in flight on the context's own stream reads the arrays about to be overwritten
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_scene = false;
 
     std::vector<DPrim> prims((size_t)n_prims);
     std::vector<float4> sph;
@@ -1385,8 +1408,7 @@ RT_API int rt_upload_lights(rt_ctx *ctx, int n_lights, const rt_light *h_lights)
     if (!ctx) return RT_ERR_INVALID;
     if (n_lights < 0 || (n_lights > 0 && !h_lights)) return fail(ctx, RT_ERR_INVALID, "bad light array");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->d_lights) (void)hipFree(ctx->d_lights);
-    ctx->d_lights = nullptr;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_lights = 0;
     if (n_lights == 0) return RT_OK;
     std::vector<DLight> l((size_t)n_lights);
@@ -1396,8 +1418,8 @@ RT_API int rt_upload_lights(rt_ctx *ctx, int n_lights, const rt_light *h_lights)
         l[i].ambient = make_float4(h.ambient[0], h.ambient[1], h.ambient[2], 0);
         l[i].diffuse = make_float4(h.diffuse[0], h.diffuse[1], h.diffuse[2], 0);
     }
-    HIP_TRY(ctx, hipMalloc(&ctx->d_lights, l.size() * sizeof(DLight)));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_lights, l.data(), l.size() * sizeof(DLight), hipMemcpyHostToDevice));
+    int rc = to_device(ctx, &ctx->d_lights, l);
+    if (rc != RT_OK) return rc;
     ctx->n_lights = n_lights;
     return RT_OK;
 }
@@ -1515,43 +1537,58 @@ RT_API int rt_render_noalloc(rt_ctx *ctx, const rt_params *p, void *d_rgba, void
     return render_impl(ctx, p, d_rgba, d_accum, d_rays, stream, reinterpret_cast<unsigned *>(slot));
 }
 
+namespace {
+// Renders `p` into the context's own frame buffers on its own stream; asynchronous.  The kernel is
+// bracketed by ev_start / ev_stop.  With `h_accum_in` the radiance sums continue from it.
+int render_into_frame(rt_ctx *ctx, const rt_params *p, bool want_accum, const float *h_accum_in) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // whole strips, so that a plain frame (strip_stride 1) and a compact one have the same layout
+    const size_t rows = ((size_t)rt_output_rows(p) + RT_STRIP_ROWS - 1) / RT_STRIP_ROWS * RT_STRIP_ROWS;
+    const size_t npx = rows * (size_t)p->width;
+    HIP_TRY(ctx, reserve(ctx, &ctx->frame_rgba, npx * 4));
+    if (want_accum) HIP_TRY(ctx, reserve(ctx, &ctx->frame_accum, npx * 16));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->frame_rays, 0, 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->frame_rgba, 0, npx * 4, ctx->stream));
+    if (want_accum) {
+        if (h_accum_in)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->frame_accum, h_accum_in, (size_t)rt_output_rows(p) * (size_t)p->width * 16,
+                                        hipMemcpyHostToDevice, ctx->stream));
+        else
+            HIP_TRY(ctx, hipMemsetAsync(ctx->frame_accum, 0, npx * 16, ctx->stream));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    int rc = rt_render(ctx, p, ctx->frame_rgba, want_accum ? ctx->frame_accum : nullptr, ctx->frame_rays, ctx->stream);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    return RT_OK;
+}
+} // namespace
+
 RT_API int rt_render_host(rt_ctx *ctx, const rt_params *p, uint8_t *h_rgba, float *h_accum, uint64_t *h_rays) {
     int rc = check_params(ctx, p);
     if (rc != RT_OK) return rc;
     if (!h_rgba) return fail(ctx, RT_ERR_INVALID, "h_rgba is null");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    size_t npx = (size_t)rt_output_rows(p) * (size_t)p->width;
+    if ((p->flags & RT_FLAG_ACCUMULATE) && !h_accum)
+        return fail(ctx, RT_ERR_INVALID, "RT_FLAG_ACCUMULATE needs h_accum");
+    const size_t npx = (size_t)rt_output_rows(p) * (size_t)p->width;
     if (npx == 0) {
         if (h_rays) *h_rays = 0;
         return RT_OK;
     }
-    void *d_rgba = nullptr, *d_accum = nullptr;
-    uint64_t *d_rays = nullptr;
-    hipError_t e = hipMalloc(&d_rgba, npx * 4);
-    if (e == hipSuccess && (h_accum || (p->flags & RT_FLAG_ACCUMULATE))) e = hipMalloc(&d_accum, npx * 16);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_rays, 8);
-    if (e == hipSuccess) e = hipMemset(d_rays, 0, 8);
-    if (e == hipSuccess) e = hipMemset(d_rgba, 0, npx * 4);
-    if (e == hipSuccess && d_accum) {
-        if ((p->flags & RT_FLAG_ACCUMULATE) && h_accum)
-            e = hipMemcpy(d_accum, h_accum, npx * 16, hipMemcpyHostToDevice);
-        else
-            e = hipMemset(d_accum, 0, npx * 16);
-    }
-    if (e == hipSuccess) {
-        rc = rt_render(ctx, p, d_rgba, d_accum, d_rays, nullptr);
-        if (rc == RT_OK) e = hipDeviceSynchronize();
-        if (rc == RT_OK && e == hipSuccess) e = hipMemcpy(h_rgba, d_rgba, npx * 4, hipMemcpyDeviceToHost);
-        if (rc == RT_OK && e == hipSuccess && h_accum) e = hipMemcpy(h_accum, d_accum, npx * 16, hipMemcpyDeviceToHost);
-        if (rc == RT_OK && e == hipSuccess && h_rays) e = hipMemcpy(h_rays, d_rays, 8, hipMemcpyDeviceToHost);
-    }
-    if (d_rgba) (void)hipFree(d_rgba);
-    if (d_accum) (void)hipFree(d_accum);
-    if (d_rays) (void)hipFree(d_rays);
+    const bool accumulate = (p->flags & RT_FLAG_ACCUMULATE) != 0;
+    rc = render_into_frame(ctx, p, h_accum != nullptr, accumulate ? h_accum : nullptr);
     if (rc != RT_OK) return rc;
-    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("rt_render_host: ") + hipGetErrorString(e));
+    HIP_TRY(ctx, hipMemcpyAsync(h_rgba, ctx->frame_rgba, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_accum) HIP_TRY(ctx, hipMemcpyAsync(h_accum, ctx->frame_accum, npx * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_rays) HIP_TRY(ctx, hipMemcpyAsync(h_rays, ctx->frame_rays, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev_start, ctx->ev_stop));
     return RT_OK;
 }
+
+RT_API uint64_t rt_device_allocations(const rt_ctx *ctx) { return ctx ? ctx->n_allocs : 0; }
+
+RT_API float rt_last_kernel_ms(const rt_ctx *ctx) { return ctx ? ctx->last_kernel_ms : 0.f; }
 
 RT_API int rt_first_hit_ex(rt_ctx *ctx, int n_rays, const float *d_org, const float *d_dir, float tmin,
                            uint32_t flags, int32_t *d_id, float *d_t, float *d_normal, uint8_t *d_front,
@@ -1603,26 +1640,27 @@ RT_API int rt_first_hit_ex_host(rt_ctx *ctx, int n_rays, const float *h_org, con
     if (n_rays == 0) return RT_OK;
     if (!h_org || !h_dir || !h_id) return fail(ctx, RT_ERR_INVALID, "null ray/id array");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    size_t n = (size_t)n_rays;
-    DevBuf org, dir, id, t, nrm, fr, ex;
-    HIP_TRY(ctx, org.alloc(n * 12));
-    HIP_TRY(ctx, dir.alloc(n * 12));
-    HIP_TRY(ctx, id.alloc(n * 4));
-    HIP_TRY(ctx, t.alloc(n * 4));
-    HIP_TRY(ctx, nrm.alloc(n * 12));
-    HIP_TRY(ctx, fr.alloc(n));
-    HIP_TRY(ctx, ex.alloc(n));
-    HIP_TRY(ctx, hipMemcpy(org.p, h_org, n * 12, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(dir.p, h_dir, n * 12, hipMemcpyHostToDevice));
-    int rc = rt_first_hit_ex(ctx, n_rays, (const float *)org.p, (const float *)dir.p, tmin, flags, (int32_t *)id.p,
-                             (float *)t.p, (float *)nrm.p, (uint8_t *)fr.p, (uint8_t *)ex.p, nullptr);
+    const size_t n = (size_t)n_rays;
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_org, n * 12));
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_dir, n * 12));
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_id, n * 4));
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_t, n * 4));
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_nrm, n * 12));
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_front, n));
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_exp, n));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->fh_org, h_org, n * 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->fh_dir, h_dir, n * 12, hipMemcpyHostToDevice, st));
+    int rc = rt_first_hit_ex(ctx, n_rays, (const float *)ctx->fh_org, (const float *)ctx->fh_dir, tmin, flags,
+                             (int32_t *)ctx->fh_id, (float *)ctx->fh_t, (float *)ctx->fh_nrm, (uint8_t *)ctx->fh_front,
+                             (uint8_t *)ctx->fh_exp, st);
     if (rc != RT_OK) return rc;
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, hipMemcpy(h_id, id.p, n * 4, hipMemcpyDeviceToHost));
-    if (h_t) HIP_TRY(ctx, hipMemcpy(h_t, t.p, n * 4, hipMemcpyDeviceToHost));
-    if (h_normal) HIP_TRY(ctx, hipMemcpy(h_normal, nrm.p, n * 12, hipMemcpyDeviceToHost));
-    if (h_front) HIP_TRY(ctx, hipMemcpy(h_front, fr.p, n, hipMemcpyDeviceToHost));
-    if (h_expanded) HIP_TRY(ctx, hipMemcpy(h_expanded, ex.p, n, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpyAsync(h_id, ctx->fh_id, n * 4, hipMemcpyDeviceToHost, st));
+    if (h_t) HIP_TRY(ctx, hipMemcpyAsync(h_t, ctx->fh_t, n * 4, hipMemcpyDeviceToHost, st));
+    if (h_normal) HIP_TRY(ctx, hipMemcpyAsync(h_normal, ctx->fh_nrm, n * 12, hipMemcpyDeviceToHost, st));
+    if (h_front) HIP_TRY(ctx, hipMemcpyAsync(h_front, ctx->fh_front, n, hipMemcpyDeviceToHost, st));
+    if (h_expanded) HIP_TRY(ctx, hipMemcpyAsync(h_expanded, ctx->fh_exp, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
     return RT_OK;
 }
 
@@ -1672,5 +1710,309 @@ RT_API int rt_scatter_host(rt_ctx *ctx, int n, const uint32_t *h_mat, const floa
     HIP_TRY(ctx, hipMemcpy(h_out_org, oo.p, N * 12, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(h_out_dir, od.p, N * 12, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(h_scattered_flag, fl.p, N, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Device groups: one frame rendered by several GPUs of one process.
+//
+// Pixels are independent (the reference's own OpenMP loop over pixels, src/Camera.cpp:80-87, relies
+// on it) and random streams are keyed on the global pixel id, so member i of n renders strips
+// i, i+n, ... of the frame compactly on its own stream, the strips travel to the first member's
+// GPU (RCCL send/recv over xGMI between distinct GPUs; plain device copies when a GPU appears
+// more than once in the list), and one kernel there deals them back into row order.
+// ---------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <chrono>
+
+namespace {
+
+// the few RCCL entry points the gather needs, bound at run time: a process that renders on one GPU
+// never loads the library
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load() {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        Send = reinterpret_cast<decltype(Send)>(dlsym(lib, "ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(dlsym(lib, "ncclRecv"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+    }
+};
+
+// dst holds whole strips in row order; src holds the cnt strips r, r+n, ... back to back
+__global__ void assemble_strips(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int words_per_strip, int cnt,
+                                int r, int n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)cnt * words_per_strip) return;
+    const int k = (int)(i / words_per_strip), w = (int)(i - (long long)k * words_per_strip);
+    dst[(size_t)(r + k * n) * (size_t)words_per_strip + (size_t)w] = src[i];
+}
+
+} // namespace
+
+struct rt_group {
+    std::vector<rt_ctx *> m; // member i renders strips i, i + size, ...
+    std::vector<int> dev;
+    std::string err;
+    enum { COPY, RCCL, RCCL_LOOPBACK } transport = COPY;
+    RcclApi rccl;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipEvent_t> done;
+    void *gather = nullptr; // on member 0's GPU: the compact strips of every member, back to back
+    void *frame = nullptr;  // on member 0's GPU: the assembled frame, whole strips
+};
+
+namespace {
+int gfail(rt_group *g, int code, const std::string &msg) {
+    if (g) g->err = msg;
+    return code;
+}
+#define GROUP_TRY(g, expr)                                                                             \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return gfail(g, RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define NCCL_TRY(g, expr)                                                                              \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess) return gfail(g, RT_ERR_HIP, std::string(#expr) + ": " + g->rccl.GetErrorString(r_)); \
+    } while (0)
+} // namespace
+
+RT_API int rt_group_create(int n_members, const int *devices, rt_group **out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    if (n_members <= 0 || n_members > 64 || !devices) return RT_ERR_INVALID;
+    rt_group *g = new (std::nothrow) rt_group();
+    if (!g) return RT_ERR_INVALID;
+    bool distinct = true;
+    for (int i = 0; i < n_members; ++i) {
+        rt_ctx *c = nullptr;
+        int rc = rt_create(devices[i], &c);
+        if (rc != RT_OK) {
+            rt_group_destroy(g);
+            return rc;
+        }
+        g->m.push_back(c);
+        g->dev.push_back(devices[i]);
+        for (int j = 0; j < i; ++j) distinct = distinct && devices[j] != devices[i];
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            rt_group_destroy(g);
+            return RT_ERR_HIP;
+        }
+        g->done.push_back(e);
+    }
+    // RCCL between distinct GPUs; RT_AMD_GROUP_TRANSPORT=copy forces peer copies, =rccl-loopback
+    // (one member only) sends the frame to itself through RCCL, which exercises the same calls
+    const char *want = getenv("RT_AMD_GROUP_TRANSPORT");
+    const bool loopback = want && strcmp(want, "rccl-loopback") == 0 && n_members == 1;
+    if ((distinct && n_members > 1 && !(want && strcmp(want, "copy") == 0)) || loopback) {
+        if (g->rccl.load()) {
+            g->comms.resize((size_t)n_members);
+            if (g->rccl.CommInitAll(g->comms.data(), n_members, devices) == ncclSuccess)
+                g->transport = loopback ? rt_group::RCCL_LOOPBACK : rt_group::RCCL;
+            else
+                g->comms.clear();
+        }
+        if (g->transport == rt_group::COPY && want && strncmp(want, "rccl", 4) == 0) {
+            rt_group_destroy(g);
+            return RT_ERR_HIP; // RCCL was asked for by name and is not usable
+        }
+    }
+    if (g->transport == rt_group::COPY)
+        for (int i = 1; i < n_members; ++i)
+            if (devices[i] != devices[0]) {
+                // direct peer writes when the link allows them; the copy works (staged) without
+                (void)hipSetDevice(devices[i]);
+                (void)hipDeviceEnablePeerAccess(devices[0], 0);
+                (void)hipGetLastError();
+            }
+    *out = g;
+    return RT_OK;
+}
+
+RT_API void rt_group_destroy(rt_group *g) {
+    if (!g) return;
+    for (ncclComm_t c : g->comms)
+        if (c) (void)g->rccl.CommDestroy(c);
+    for (size_t i = 0; i < g->done.size(); ++i)
+        if (g->done[i]) (void)hipEventDestroy(g->done[i]);
+    for (rt_ctx *c : g->m) rt_destroy(c); // frees g->gather / g->frame with member 0's buffers
+    delete g;
+}
+
+RT_API const char *rt_group_last_error(const rt_group *g) { return g ? g->err.c_str() : "null group"; }
+RT_API int rt_group_size(const rt_group *g) { return g ? (int)g->m.size() : 0; }
+RT_API const char *rt_group_transport(const rt_group *g) {
+    if (!g) return "";
+    return g->transport == rt_group::COPY ? "copy" : (g->transport == rt_group::RCCL ? "rccl" : "rccl-loopback");
+}
+RT_API uint64_t rt_group_device_allocations(const rt_group *g) {
+    uint64_t n = 0;
+    if (g)
+        for (const rt_ctx *c : g->m) n += c->n_allocs;
+    return n;
+}
+
+RT_API int rt_group_upload_scene_ex(rt_group *g, int n_prims, const rt_prim *h_prims, int n_vertices,
+                                    const float *h_vertices, int n_mats, const rt_material *h_mats) {
+    if (!g) return RT_ERR_INVALID;
+    for (rt_ctx *c : g->m) {
+        int rc = rt_upload_scene_ex(c, n_prims, h_prims, n_vertices, h_vertices, n_mats, h_mats);
+        if (rc != RT_OK) return gfail(g, rc, c->err);
+    }
+    return RT_OK;
+}
+
+RT_API int rt_group_upload_lights(rt_group *g, int n_lights, const rt_light *h_lights) {
+    if (!g) return RT_ERR_INVALID;
+    for (rt_ctx *c : g->m) {
+        int rc = rt_upload_lights(c, n_lights, h_lights);
+        if (rc != RT_OK) return gfail(g, rc, c->err);
+    }
+    return RT_OK;
+}
+
+RT_API int rt_group_set_camera(rt_group *g, const rt_camera *cam) {
+    if (!g) return RT_ERR_INVALID;
+    for (rt_ctx *c : g->m) {
+        int rc = rt_set_camera(c, cam);
+        if (rc != RT_OK) return gfail(g, rc, c->err);
+    }
+    return RT_OK;
+}
+
+RT_API int rt_group_render(rt_group *g, const rt_params *p, void **d_frame, uint64_t *h_rays, rt_group_timing *timing) {
+    if (!g) return RT_ERR_INVALID;
+    if (!p) return gfail(g, RT_ERR_INVALID, "params is null");
+    if (p->strip_first != 0 || p->strip_stride != 1)
+        return gfail(g, RT_ERR_INVALID, "a group deals the strips itself: strip_first must be 0 and strip_stride 1");
+    if (p->flags & RT_FLAG_ACCUMULATE) return gfail(g, RT_ERR_UNSUPPORTED, "a group renders RGBA8 frames only");
+    const int n = (int)g->m.size();
+    rt_ctx *root = g->m[0];
+    const auto t_begin = std::chrono::steady_clock::now();
+
+    // every member renders its strips on its own stream
+    std::vector<rt_params> mp((size_t)n, *p);
+    std::vector<size_t> bytes((size_t)n), offset((size_t)n);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        mp[i].strip_first = i;
+        mp[i].strip_stride = n;
+        int rc = check_params(g->m[i], &mp[i]);
+        if (rc != RT_OK) return gfail(g, rc, g->m[i]->err);
+    }
+    const size_t strip_bytes = (size_t)RT_STRIP_ROWS * (size_t)p->width * 4;
+    const int strips = (p->height + RT_STRIP_ROWS - 1) / RT_STRIP_ROWS;
+    for (int i = 0; i < n; ++i) {
+        bytes[i] = (size_t)local_strips(&mp[i]) * strip_bytes;
+        offset[i] = total;
+        total += bytes[i];
+        if (bytes[i] == 0) continue;
+        // a lone member renders the plain row-major frame (its compact layout equals it but for the
+        // rows of a last partial strip)
+        int rc = render_into_frame(g->m[i], &mp[i], false, nullptr);
+        if (rc != RT_OK) return gfail(g, rc, g->m[i]->err);
+    }
+
+    GROUP_TRY(g, hipSetDevice(g->dev[0]));
+    GROUP_TRY(g, reserve(root, &g->frame, (size_t)strips * strip_bytes));
+    GROUP_TRY(g, reserve(root, &g->gather, total));
+    const int first_moved = g->transport == rt_group::RCCL_LOOPBACK ? 0 : 1;
+    if (g->transport == rt_group::COPY) {
+        for (int r = 1; r < n; ++r) {
+            if (bytes[r] == 0) continue;
+            GROUP_TRY(g, hipSetDevice(g->dev[r]));
+            char *dst = static_cast<char *>(g->gather) + offset[r];
+            if (g->dev[r] == g->dev[0])
+                GROUP_TRY(g, hipMemcpyAsync(dst, g->m[r]->frame_rgba, bytes[r], hipMemcpyDeviceToDevice, g->m[r]->stream));
+            else
+                GROUP_TRY(g, hipMemcpyPeerAsync(dst, g->dev[0], g->m[r]->frame_rgba, g->dev[r], bytes[r], g->m[r]->stream));
+            GROUP_TRY(g, hipEventRecord(g->done[r], g->m[r]->stream));
+            GROUP_TRY(g, hipSetDevice(g->dev[0]));
+            GROUP_TRY(g, hipStreamWaitEvent(root->stream, g->done[r], 0));
+        }
+    } else {
+        // one grouped exchange: the root posts a receive per member, every member one send
+        NCCL_TRY(g, g->rccl.GroupStart());
+        for (int r = first_moved; r < n; ++r) {
+            if (bytes[r] == 0) continue;
+            NCCL_TRY(g, g->rccl.Recv(static_cast<char *>(g->gather) + offset[r], bytes[r], ncclUint8, r, g->comms[0],
+                                     root->stream));
+            NCCL_TRY(g, g->rccl.Send(g->m[r]->frame_rgba, bytes[r], ncclUint8, 0, g->comms[r], g->m[r]->stream));
+        }
+        NCCL_TRY(g, g->rccl.GroupEnd());
+    }
+    GROUP_TRY(g, hipSetDevice(g->dev[0]));
+    const int wps = (int)(strip_bytes / 16);
+    for (int r = 0; r < n; ++r) {
+        const int cnt = (int)(bytes[r] / strip_bytes);
+        if (cnt == 0) continue;
+        const void *src = r < first_moved ? root->frame_rgba : static_cast<char *>(g->gather) + offset[r];
+        const long long words = (long long)cnt * wps;
+        hipLaunchKernelGGL(assemble_strips, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, root->stream,
+                           static_cast<uint4 *>(g->frame), static_cast<const uint4 *>(src), wps, cnt, r, n);
+    }
+    GROUP_TRY(g, hipGetLastError());
+    // all members' work has been ordered into the root stream (events / RCCL); wait for it, then for
+    // the members' own streams, which by then have nothing left but to report
+    GROUP_TRY(g, hipStreamSynchronize(root->stream));
+    uint64_t rays = 0;
+    float kmin = 1e30f, kmax = 0.f;
+    for (int i = 0; i < n; ++i) {
+        if (bytes[i] == 0) continue;
+        GROUP_TRY(g, hipSetDevice(g->dev[i]));
+        GROUP_TRY(g, hipStreamSynchronize(g->m[i]->stream));
+        uint64_t r = 0;
+        GROUP_TRY(g, hipMemcpy(&r, g->m[i]->frame_rays, 8, hipMemcpyDeviceToHost));
+        rays += r;
+        GROUP_TRY(g, hipEventElapsedTime(&g->m[i]->last_kernel_ms, g->m[i]->ev_start, g->m[i]->ev_stop));
+        kmin = fminf(kmin, g->m[i]->last_kernel_ms);
+        kmax = fmaxf(kmax, g->m[i]->last_kernel_ms);
+    }
+    GROUP_TRY(g, hipSetDevice(g->dev[0]));
+    if (h_rays) *h_rays = rays;
+    if (d_frame) *d_frame = g->frame;
+    if (timing) {
+        timing->kernel_ms_min = kmin;
+        timing->kernel_ms_max = kmax;
+        timing->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        timing->gather_ms = timing->total_ms - kmax; // launch, exchange, assembly and the waits around them
+    }
+    return RT_OK;
+}
+
+RT_API int rt_group_render_host(rt_group *g, const rt_params *p, uint8_t *h_rgba, uint64_t *h_rays,
+                                rt_group_timing *timing) {
+    if (!g) return RT_ERR_INVALID;
+    if (!h_rgba) return gfail(g, RT_ERR_INVALID, "h_rgba is null");
+    const auto t_begin = std::chrono::steady_clock::now();
+    void *d_frame = nullptr;
+    int rc = rt_group_render(g, p, &d_frame, h_rays, timing);
+    if (rc != RT_OK) return rc;
+    GROUP_TRY(g, hipMemcpy(h_rgba, d_frame, (size_t)p->width * (size_t)p->height * 4, hipMemcpyDeviceToHost));
+    if (timing) {
+        timing->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        timing->gather_ms = timing->total_ms - timing->kernel_ms_max;
+    }
     return RT_OK;
 }

@@ -761,3 +761,52 @@ def test_general_first_hit_on_random_primitive_soups(renderer, oracle64, seed):
         assert np.array_equal(front[hit], ofront[hit])
         assert np.all(np.abs(t[hit] - ot[hit]) <= 1e-5 * np.abs(ot[hit]) + 1e-7)
         assert np.max(np.abs(nrm[hit] - onrm[hit])) <= 1e-5
+
+
+# --------------------------------------------------------------------------
+# device groups (rt_group_*): the native single-process multi-GPU path
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("devices,transport", [([0], None), ([0, 0, 0], None), ([0, 0], None), ([0], "rccl-loopback")])
+@pytest.mark.parametrize("scene_name,W,H,spp", [("random_spheres", 160, 90, 8), ("mixed_lit", 96, 10, 4)])
+def test_group_render_equals_plain_render(renderer, monkeypatch, devices, transport, scene_name, W, H, spp):
+    """Strips rendered by the members of a group (here: several contexts on the one GPU of the box, or
+    one member sending to itself through RCCL) and gathered on the first equal the plain frame byte
+    for byte; H = 90 ends in a partial strip, H = 10 leaves the third member without work."""
+    from raytracer_amd import Group
+
+    scene = scenes.by_name(scene_name)
+    flags = 2 if scene_name == "mixed_lit" else 0
+    p = RenderParams(W, H, samples_per_pixel=spp, max_depth=12, seed=5, flags=flags)
+    renderer.set_scene(scene)
+    want, _, want_rays = renderer.render_host(p)
+    if transport:
+        monkeypatch.setenv("RT_AMD_GROUP_TRANSPORT", transport)
+    with Group(devices) as g:
+        assert g.transport == (transport or "copy")
+        g.set_scene(scene)
+        got, rays, t = g.render_host(p)
+        assert np.array_equal(got, want)
+        assert rays == want_rays
+        assert 0 < t["kernel_ms_min"] <= t["kernel_ms_max"] <= t["total_ms"]
+        # a second frame of the unchanged scene allocates nothing
+        before = g.device_allocations()
+        got2, _, _ = g.render_host(p)
+        assert g.device_allocations() == before
+        assert np.array_equal(got2, want)
+
+
+def test_second_frame_allocates_nothing(renderer):
+    """Buffers are kept and only grown: re-uploading the same scene and rendering the same frame again
+    issues no hipMalloc (rt_device_allocations), and changes no byte."""
+    scene = scenes.small_scene()
+    renderer.set_scene(scene)
+    p = RenderParams(128, 72, samples_per_pixel=8, max_depth=10, seed=2)
+    a, _, _ = renderer.render_host(p)
+    ids = renderer.first_hit(np.zeros((4, 3), np.float32), np.tile(np.float32([0, 0, 1]), (4, 1)))[0]
+    before = renderer.device_allocations()
+    renderer.set_scene(scene)
+    b, _, _ = renderer.render_host(p)
+    ids2 = renderer.first_hit(np.zeros((4, 3), np.float32), np.tile(np.float32([0, 0, 1]), (4, 1)))[0]
+    assert renderer.device_allocations() == before
+    assert np.array_equal(a, b) and np.array_equal(ids, ids2)
+    assert renderer.last_kernel_ms() > 0
