@@ -36,6 +36,9 @@ struct FlatScene {
 
 FlatScene flattenScene(const SceneManager &sceneManager, bool withLights);
 
+// Byte-wise equality of two flattened scenes: what decides whether the device copy is still current.
+bool sameFlatScene(const FlatScene &a, const FlatScene &b);
+
 // rt_upload_scene_ex + rt_upload_lights; throws BackendError on failure.
 void uploadScene(rt_ctx *ctx, const FlatScene &flat);
 

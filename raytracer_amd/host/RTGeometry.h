@@ -1,66 +1,60 @@
-// RTGeometry.h — the plain value types of the render path (reference inc/RTGeometry.h:36-90).
+// RTGeometry.h — plain value types that cross the render path's host interface
+// (reference inc/RTGeometry.h:36-90: Ray, HitRecord, Interval).  The reflection / refraction helpers
+// of that header (:18-34) are evaluated on the GPU only (csrc/rt_device.h) and have no host copy.
 #ifndef RTAMD_RTGEOMETRY_H
 #define RTAMD_RTGEOMETRY_H
 
-#include <algorithm>
-#include <cmath>
 #include <limits>
 
 #include "Vec3.h"
 
 namespace rtamd {
 
-// Mirror reflection and Snell refraction as the materials use them (reference inc/RTGeometry.h:18-34),
-// for host code that wants the same formulas; the render path evaluates them on the GPU.
-inline gm::IVec3f reflect(const gm::IVec3f &v, const gm::IVec3f &n) { return v - n * 2 * dot(v, n); }
-
-inline gm::IVec3f refract(const gm::IVec3f &uv, const gm::IVec3f &n, double refractionCoef) {
-    gm::IVec3f unitUv = uv.normalized();
-    double cosTheta = std::fmin(dot(unitUv * (-1), n), 1.0);
-    gm::IVec3f rOutPerp = (unitUv + n * cosTheta) * refractionCoef;
-    // the reference rescales an over-long perpendicular part by 1/coef^2 (:28) and then asserts (:30);
-    // here the square root is clamped at zero instead of asserting
-    if (1.0 - rOutPerp.length2() < 0) rOutPerp = rOutPerp * (1.0 / (refractionCoef * refractionCoef));
-    gm::IVec3f rOutParallel = n * (-std::sqrt(std::max(0.0, 1.0 - rOutPerp.length2())));
-    return rOutPerp + rOutParallel;
-}
-
-struct Ray {
-    gm::IPoint3 origin;
-    gm::IVec3f direction;
-    Ray() {}
-    Ray(const gm::IPoint3 &origin, const gm::IVec3f &direction) : origin(origin), direction(direction) {}
-    gm::IPoint3 at(double t) const { return origin + direction * t; }
-};
-
 struct RTMaterial;
 class Primitives;
 
-// What a closest-hit query reports (reference inc/RTGeometry.h:49-62).  `object` is null for cubes
-// and polygons, as in the reference (inc/RTObjects.h:507,642).
-struct HitRecord {
-    gm::IPoint3 point = {};
-    gm::IVec3f normal = {};
-    const RTMaterial *material = nullptr;
-    const Primitives *object = nullptr;
-    bool frontFace = false;
-    double time = 0;
-    bool hitExpanded = false;
+// Half-line origin + t * direction; the direction need not be unit length
+// (SphereObject::hitDetail divides by its squared length, reference inc/RTObjects.h:136).
+struct Ray {
+    gm::IPoint3 origin;
+    gm::IVec3f direction;
+
+    Ray() = default;
+    Ray(const gm::IPoint3 &from, const gm::IVec3f &along) : origin(from), direction(along) {}
+    gm::IPoint3 at(double t) const { return origin + direction * t; }
 };
 
+// Open / closed ranges of the ray parameter.  hitClosest searches the OPEN range (surrounds).
 struct Interval {
-    double min, max;
-    Interval() : min(+std::numeric_limits<double>::infinity()), max(-std::numeric_limits<double>::infinity()) {}
-    Interval(double min, double max) : min(min), max(max) {}
-    double size() const { return max - min; }
-    bool contains(double x) const { return min <= x && x <= max; }
-    bool surrounds(double x) const { return min < x && x < max; }
+    double min = +std::numeric_limits<double>::infinity(); // default: empty
+    double max = -std::numeric_limits<double>::infinity();
+
+    Interval() = default;
+    Interval(double lo, double hi) : min(lo), max(hi) {}
+
+    bool surrounds(double x) const { return x > min && x < max; }
+    bool contains(double x) const { return x >= min && x <= max; }
     double clamp(double x) const { return x < min ? min : (x > max ? max : x); }
-    static const Interval empty, universe; // as in the reference (inc/RTGeometry.h:89)
+    double size() const { return max - min; }
+
+    static const Interval empty, universe;
 };
-inline const Interval Interval::empty = Interval();
-inline const Interval Interval::universe =
-    Interval(-std::numeric_limits<double>::infinity(), +std::numeric_limits<double>::infinity());
+inline const Interval Interval::empty{};
+inline const Interval Interval::universe{-std::numeric_limits<double>::infinity(),
+                                         +std::numeric_limits<double>::infinity()};
+
+// Result of a closest-hit query (reference inc/RTGeometry.h:49-62).  `object` stays null for cubes
+// and polygons, as in the reference (inc/RTObjects.h:507,642); `hitExpanded` marks a hit on the
+// grown shell of a selected object.
+struct HitRecord {
+    double time = 0;
+    gm::IPoint3 point{};
+    gm::IVec3f normal{}; // unit, against the ray
+    bool frontFace = false;
+    bool hitExpanded = false;
+    const RTMaterial *material = nullptr;
+    const Primitives *object = nullptr;
+};
 
 } // namespace rtamd
 #endif

@@ -126,7 +126,7 @@ public:
     explicit RTEmissive(const gm::IVec3f &emission) { emission_ = emission; }
     RTMaterialKind kind() const override { return RTMaterialKind::Emissive; }
     std::string typeString() const override { return "Emissive"; }
-    bool hasEmmision() const override { return true; }
+    // hasEmmision() stays false, as in the reference, which does not override it (inc/RTMaterial.h:28,200-221)
 };
 
 // Owning factory, reference inc/RTMaterial.h:223-248.

@@ -16,8 +16,11 @@ namespace rtamd {
 class SceneManager {
     std::vector<Primitives *> primitives_;
     std::vector<Light *> directLightSources_;
-    mutable rt_ctx *ctx_ = nullptr; // created by the first hitClosest
+    // device side of hitClosest: created by the first query, re-uploaded only when the scene changed
+    mutable rt_ctx *ctx_ = nullptr;
     mutable int ctxDevice_ = -1;
+    mutable FlatScene uploaded_;
+    mutable bool haveUploaded_ = false;
 
 public:
     SceneManager() = default;
@@ -33,8 +36,9 @@ public:
     void clear();
 
     // Closest hit of one ray, with the reference's signature and record (src/RayTracer.cpp:68-100):
-    // the scene is flattened and uploaded on every call and one ray is traced on the GPU with the
-    // double-precision refinement on, so the primitive picked is the one a double evaluation picks.
+    // one ray is traced on the GPU with the double-precision refinement on, so the primitive picked is
+    // the one a double evaluation picks.  The scene is flattened on every call (that is how edits are
+    // noticed) but uploaded only when it differs from what the device holds.
     // Meant for picking (a mouse click), not for loops: use the batch form for many rays.
     // Throws BackendError when no GPU is usable or the scene holds an unknown primitive kind.
     bool hitClosest(const Ray &ray, Interval rayTime, HitRecord &hitRecord, bool hitExpandedState) const;
@@ -42,6 +46,7 @@ public:
     void hitClosest(const std::vector<Ray> &rays, Interval rayTime, bool hitExpandedState,
                     std::vector<HitRecord> &records, std::vector<char> &hit) const;
     int device = 0; // which GPU hitClosest uses (not in the reference)
+    uint64_t deviceAllocations() const; // hipMalloc calls made for hitClosest so far (not in the reference)
 
     const std::vector<Light *> &inderectLightSources() const { return directLightSources_; }
     std::vector<Primitives *> &primitives() { return primitives_; }

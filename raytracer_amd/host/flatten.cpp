@@ -1,4 +1,5 @@
 // Flattening of the host-side scene graph into the arrays of the C ABI (include/rt_amd.h).
+#include <cstring>
 #include <map>
 
 #include "Backend.h"
@@ -93,6 +94,18 @@ FlatScene flattenScene(const SceneManager &sceneManager, bool withLights) {
         }
     }
     return flat;
+}
+
+namespace {
+template <typename T>
+bool sameBytes(const std::vector<T> &a, const std::vector<T> &b) {
+    return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0);
+}
+} // namespace
+
+bool sameFlatScene(const FlatScene &a, const FlatScene &b) {
+    return sameBytes(a.prims, b.prims) && sameBytes(a.verts, b.verts) && sameBytes(a.mats, b.mats) &&
+           sameBytes(a.lights, b.lights);
 }
 
 void uploadScene(rt_ctx *ctx, const FlatScene &flat) {

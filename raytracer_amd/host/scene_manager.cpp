@@ -14,6 +14,8 @@ SceneManager::~SceneManager() {
     if (ctx_) rt_destroy(ctx_);
 }
 
+uint64_t SceneManager::deviceAllocations() const { return ctx_ ? rt_device_allocations(ctx_) : 0; }
+
 void SceneManager::addObject(gm::IPoint3 position, Primitives *object) {
     assert(object);
     assert((object->parent_ == this || object->parent_ == nullptr) && "addObject failed : object parent != this or nullptr");
@@ -53,15 +55,21 @@ void SceneManager::hitClosest(const std::vector<Ray> &rays, Interval rayTime, bo
     hit.assign(n, 0);
     if (n == 0) return;
     if (n > 0x7fffffffu) throw BackendError(RT_ERR_INVALID, "SceneManager::hitClosest: too many rays");
-    const FlatScene flat = flattenScene(*this, false);
+    FlatScene flat = flattenScene(*this, false);
     if (!ctx_ || ctxDevice_ != device) {
         if (ctx_) rt_destroy(ctx_);
         ctx_ = nullptr;
+        haveUploaded_ = false;
         int rc = rt_create(device, &ctx_);
         if (rc != RT_OK) throw BackendError(rc, "rt_create failed (no usable GPU?)");
         ctxDevice_ = device;
     }
-    uploadScene(ctx_, flat);
+    if (!(haveUploaded_ && sameFlatScene(flat, uploaded_))) {
+        haveUploaded_ = false;
+        uploadScene(ctx_, flat);
+        uploaded_ = std::move(flat);
+        haveUploaded_ = true;
+    }
     std::vector<float> org(3 * n), dir(3 * n), t(n), nrm(3 * n);
     std::vector<int32_t> id(n);
     std::vector<uint8_t> front(n), expanded(n);
@@ -90,7 +98,7 @@ void SceneManager::hitClosest(const std::vector<Ray> &rays, Interval rayTime, bo
         r.hitExpanded = expanded[i] != 0;
         r.material = p->material();
         // cubes and polygons leave the object pointer null (reference inc/RTObjects.h:507,642)
-        const rt_prim &fp = flat.prims[(size_t)id[i]];
+        const rt_prim &fp = uploaded_.prims[(size_t)id[i]];
         r.object = (fp.type == RT_PRIM_CUBE || fp.type == RT_PRIM_POLYGON) ? nullptr : p;
         hit[i] = 1;
     }

@@ -267,6 +267,50 @@ def grid_scene(nx: int = 100, ny: int = 100, seed: int = 777) -> Scene:
     return b.build(f"grid{nx}x{ny}", make_camera((0.9 * ext, -1.1 * ext, 0.6 * ext), (-0.9, 1.1, -0.6)))
 
 
+def scene_text(scene: Scene) -> str:
+    """The scene as a scene file of the C++ host layer (SceneIO.h: the reference's one-line text records
+    of materials, primitives and lights), 9 significant digits, so that render_scene and the Camera API
+    see the floats this module holds.  Sphere-only scenes and general ones alike."""
+    f = lambda v: " ".join(f"{float(x):.9g}" for x in v)
+    cam = scene.camera[0]
+    c = cam["center"].astype(np.float64)
+    d = cam["upper_left"].astype(np.float64) + 0.5 * cam["right"].astype(np.float64) + 0.5 * cam["down"].astype(np.float64) - c
+    d = d / np.sqrt(np.dot(d, d))
+    out = ["# written by raytracer_amd.scenes.scene_text: " + scene.name, f"Camera {f(c)} {f(d)}"]
+    zero = (0.0, 0.0, 0.0)
+    for m in scene.mats:
+        t = int(m["type"])
+        if t == MAT_LAMBERTIAN:
+            out.append(f"Material Lambertian {f(m['albedo'])} {f(zero)} {f(m['emission'])}")
+        elif t == MAT_METAL:
+            out.append(f"Material Metal {f(m['diffuse'])} {f(m['albedo'])} {f(m['emission'])} {float(m['fuzz']):.9g}")
+        elif t == MAT_DIELECTRIC:
+            out.append(f"Material Dielectric {f(m['diffuse'])} {f(zero)} {f(m['emission'])} {f(m['albedo'])} "
+                       f"{float(m['ior']):.9g}")
+        else:
+            out.append(f"Material Emissive {f(m['diffuse'])} {f(zero)} {f(m['emission'])}")
+    if scene.needs_general:
+        for pr in scene.prims:
+            t, p8, sel = int(pr["type"]), pr["p"], int(pr["selected"])
+            if t == PRIM_SPHERE:
+                out.append(f"Object {int(pr['mat'])} Sphere {f(p8[:3])} {sel} {float(p8[3]):.9g}")
+            elif t == PRIM_PLANE:
+                out.append(f"Object {int(pr['mat'])} Plane {f(p8[:3])} {sel} {f(p8[3:6])}")
+            elif t == PRIM_CUBE:
+                out.append(f"Object {int(pr['mat'])} Cube {f(p8[:3])} {sel} {f(p8[3:6])}")
+            else:
+                v = scene.verts[int(pr["first_vertex"]):int(pr["first_vertex"]) + int(pr["n_vertices"])]
+                out.append(f"Object {int(pr['mat'])} Polygon {f(p8[3:6])} {sel} {len(v)} {f(v.reshape(-1))}")
+    else:
+        for sp, mi in zip(scene.spheres, scene.mat_id):
+            out.append(f"Object {int(mi)} Sphere {f((sp['cx'], sp['cy'], sp['cz']))} 0 {float(sp['r']):.9g}")
+    if scene.lights is not None:
+        for l in scene.lights:
+            out.append(f"Light {f(l['position'])} {f(l['ambient'])} {f(l['diffuse'])} {f(l['specular'])} "
+                       f"{float(l['view_pow']):.9g}")
+    return "\n".join(out) + "\n"
+
+
 def by_name(name: str) -> Scene:
     if name == "small":
         return small_scene()
