@@ -310,6 +310,11 @@ int rt_group_render_host(rt_group *g, const rt_params *p, uint8_t *h_rgba, uint6
 /* The counter-based generator the kernels use, exposed for tests:
  * fills out[4] with the four 32-bit words of stream (pixel, sample, call, seed). */
 void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint32_t out[4]);
+/* The same generator evaluated ON THE DEVICE, by the code the render kernel runs, for n keys of four
+ * words (pixel, sample, call, seed) each; h_out receives four words per key.  Host pointers,
+ * synchronous.  Stands where the reference seeds its per-thread generator per pixel and draws from it
+ * (src/Camera.cpp:84,129-130; inc/RTMaterial.h:72,111,158). */
+int rt_rng4_device_host(rt_ctx *ctx, int n, const uint32_t *h_keys, uint32_t *h_out);
 
 /* Library/ABI version (major*100 + minor). */
 int rt_version(void);

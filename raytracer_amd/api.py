@@ -82,7 +82,7 @@ class RenderParams:
 
 
 EXPORTS = [
-    "rt_version", "rt_rng4", "rt_output_rows", "rt_create", "rt_destroy", "rt_last_error",
+    "rt_version", "rt_rng4", "rt_rng4_device_host", "rt_output_rows", "rt_create", "rt_destroy", "rt_last_error",
     "rt_upload_scene", "rt_upload_scene_ex", "rt_upload_lights", "rt_set_camera", "rt_render", "rt_render_noalloc",
     "rt_render_host", "rt_last_kernel_ms", "rt_device_allocations",
     "rt_group_create", "rt_group_destroy", "rt_group_last_error", "rt_group_size", "rt_group_transport",
@@ -109,6 +109,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rt_version.restype = C.c_int
     lib.rt_rng4.argtypes = [u32, u32, u32, u32, C.POINTER(u32)]
     lib.rt_rng4.restype = None
+    lib.rt_rng4_device_host.argtypes = [vp, C.c_int, vp, vp]
+    lib.rt_rng4_device_host.restype = C.c_int
     lib.rt_output_rows.argtypes = [C.POINTER(_Params)]
     lib.rt_output_rows.restype = C.c_int
     lib.rt_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -301,6 +303,13 @@ class Renderer:
             ),
             "rt_render",
         )
+
+    def rng4_device(self, keys: np.ndarray) -> np.ndarray:
+        """The kernels' generator evaluated on the device for keys[n, 4] = (pixel, sample, call, seed)."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint32).reshape(-1, 4)
+        out = np.zeros_like(keys)
+        self._check(self.lib.rt_rng4_device_host(self.h, len(keys), _ptr(keys), _ptr(out)), "rt_rng4_device_host")
+        return out
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.rt_last_kernel_ms(self.h))

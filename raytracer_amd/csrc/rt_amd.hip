@@ -98,10 +98,7 @@ enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2 };
 // a broadcast read) for one ray.
 __device__ __forceinline__ void scan_lds(const float4 *lds, const float4 *lds_r2, int nquads, int base, const RayK &r,
                                          V3 o, V3 dh, float tmin, int self_id, float &best_t, int &best_id) {
-#ifndef RT_UNROLL
-#define RT_UNROLL 1
-#endif
-#pragma unroll RT_UNROLL
+#pragma unroll 1
     for (int q = 0; q < nquads; ++q) {
         float4 A0 = lds[4 * q], B0 = lds[4 * q + 1], A1 = lds[4 * q + 2], B1 = lds[4 * q + 3];
         test_quad(r, o, dh, A0, B0, A1, B1, lds_r2[q], tmin, base + 4 * q, self_id, best_t, best_id);
@@ -388,7 +385,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                 // the halo pass runs for primary rays only (hitExpandedState, src/Camera.cpp:141)
                 if (!shadow_ray && sc.full.n_halo > 0 && pt.depth == p.max_depth) {
                     Closest e = halo_pass(sc.full, pt.o, pt.d, TMIN);
-                    if (e.t < c.t) c = e;
+                    if (e.expanded && e.t < c.t) c = e; // a plain halo-pass hit is the normal pass's own hit
                 }
                 any_hit = c.prim >= 0;
             }
@@ -897,7 +894,7 @@ __global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const
         for (int k = 0; k < sc.full.n_others; ++k) other_hit(sc.full, sc.full.others[k], o, d, tmin, c);
         if (expanded_state && sc.full.n_halo > 0) {
             Closest e = halo_pass(sc.full, o, d, tmin);
-            if (e.t < c.t) c = e;
+            if (e.expanded && e.t < c.t) c = e; // a plain halo-pass hit is the normal pass's own hit
         }
         id[i] = c.prim;
         Hit h;
@@ -1000,6 +997,15 @@ __global__ void scatter_kernel(int n, const DMat *__restrict__ mats, const uint3
     att[3 * i] = a.x; att[3 * i + 1] = a.y; att[3 * i + 2] = a.z;
     out_org[3 * i] = o.x; out_org[3 * i + 1] = o.y; out_org[3 * i + 2] = o.z;
     out_dir[3 * i] = d.x; out_dir[3 * i + 1] = d.y; out_dir[3 * i + 2] = d.z;
+}
+
+// The generator as the render kernel evaluates it, on explicit keys (pixel, sample, call, seed).
+__global__ void rng_kernel(int n, const uint32_t *__restrict__ keys, uint32_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w0, w1, w2, w3;
+    rng4(keys[4 * i], keys[4 * i + 1], keys[4 * i + 2], keys[4 * i + 3], w0, w1, w2, w3);
+    out[4 * i] = w0; out[4 * i + 1] = w1; out[4 * i + 2] = w2; out[4 * i + 3] = w3;
 }
 
 } // namespace
@@ -1172,6 +1178,23 @@ RT_API int rt_version(void) { return 102; }
 
 RT_API void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint32_t out[4]) {
     rng4(pixel, sample, call, seed, out[0], out[1], out[2], out[3]);
+}
+
+RT_API int rt_rng4_device_host(rt_ctx *ctx, int n, const uint32_t *h_keys, uint32_t *h_out) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!h_keys || !h_out))) return fail(ctx, RT_ERR_INVALID, "bad key / output array");
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n * 16;
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_org, bytes));
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_dir, bytes));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->fh_org, h_keys, bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(rng_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                       (const uint32_t *)ctx->fh_org, (uint32_t *)ctx->fh_dir);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->fh_dir, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
 }
 
 RT_API int rt_output_rows(const rt_params *p) {

@@ -171,8 +171,13 @@ __device__ __forceinline__ void other_hit(const FullScene &fs, int idx, V3 o, V3
 // The selection-halo pass of SceneManager::hitClosest (src/RayTracer.cpp:84-97), run for primary rays:
 // every selected primitive (and every plane, whose hitExpanded is its plain hit, inc/RTObjects.h:192-194)
 // is tried in insertion order against the shrinking interval, first as itself and, failing that, grown by
-// EXPAND_COEF (sphere :96-105, polygon :370-386, cube :560-568).  The record persists across primitives
-// exactly as in the reference: a plain hit found here does not clear an earlier halo flag.
+// EXPAND_COEF (sphere :96-105, polygon :370-386, cube :560-568).
+// In the reference the record persists across primitives, so a plain hit found here keeps an earlier
+// halo flag; but such a plain hit never reaches the caller there: the normal pass found the same
+// primitive at the same t, and the tie goes to the normal record (src/RayTracer.cpp:95-99).  In single
+// precision the two passes compute that t by different formulas and the tie can break either way, so
+// here the flag is that of the final record alone and the caller takes this record only when it lies on
+// a grown shell.
 __device__ __forceinline__ Closest halo_pass(const FullScene &fs, V3 o, V3 d, float tmin) {
     Closest e;
     e.t = __builtin_inff();
@@ -205,7 +210,7 @@ __device__ __forceinline__ Closest halo_pass(const FullScene &fs, V3 o, V3 d, fl
             e.prim = idx;
             e.scale = grown ? EXPAND_COEF : 1.0f;
             e.box_face = face;
-            if (grown) e.expanded = true; // sticky, as in the reference
+            e.expanded = grown;
         }
     }
     return e;

@@ -246,6 +246,20 @@ def random_spheres_scene(seed: int = 12345) -> Scene:
     return b.build("random_spheres", make_camera((13.0, -3.0, 2.0), (-13.0, 3.0, -2.0)))
 
 
+def halo_overlap_scene() -> Scene:
+    """Two SELECTED spheres whose halos interact: the grown shell (1.05 r, reference inc/RTObjects.h:26,96-105)
+    of the big sphere A, first in insertion order, is crossed by rays that then meet the small selected
+    sphere B in front of it; an unselected sphere and the ground complete the picture."""
+    b = _Builder()
+    b.sphere((0.0, 0.0, 5.0), 1.0, b.lambertian((0.2, 0.3, 0.7)))        # 0: A
+    b.sphere((0.8, 0.0, 3.0), 0.3, b.lambertian((0.7, 0.6, 0.2)))        # 1: B, over A's silhouette
+    b.sphere((-0.9, 0.3, 3.4), 0.35, b.metal((0.8, 0.8, 0.8), 0.05))     # 2: unselected, over the other edge
+    b.sphere((0.0, -100.5, 3.0), 99.5, b.lambertian((0.5, 0.5, 0.5)))    # 3: ground
+    b.select(0)
+    b.select(1)
+    return b.build("halo_overlap", make_camera((0, 0, 0), (0, 0, 1)))
+
+
 def grid_scene(nx: int = 100, ny: int = 100, seed: int = 777) -> Scene:
     """nx*ny spheres on a unit-pitch grid (+ ground): 70 % glass, 15 % metal, 15 % diffuse."""
     g = _Lcg(seed)
@@ -326,6 +340,8 @@ def by_name(name: str) -> Scene:
         return mixed_scene(selected=True)
     if name == "mixed_lit":
         return mixed_scene(selected=True, phong=1)
+    if name == "halo_overlap":
+        return halo_overlap_scene()
     if name == "random_spheres":
         return random_spheres_scene()
     if name == "grid10k":

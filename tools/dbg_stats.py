@@ -2,8 +2,7 @@
 
 Build the instrumented library first (add -DRT_STATS_TIMES_ONLY to keep only the per-wave timing, which
 does not slow the kernel down):
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -fvisibility=hidden -DRT_STATS \
-        -o tools/v_stats.so raytracer_amd/csrc/rt_amd.hip
+  python __graft_entry__.py variant tools/v_stats.so -DRT_STATS
 usage: dbg_stats.py [scene W H spp depth]
 """
 import ctypes as C, os, sys
