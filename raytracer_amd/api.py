@@ -94,6 +94,14 @@ EXPORTS = [
 _lib = None
 
 
+def _proto(lib, name, field, value):
+    """Declares a prototype; a library built from an older source (tuning comparisons through RT_AMD_LIB)
+    may lack the newer entry points, which then fail when called, not when the library is loaded."""
+    fn = getattr(lib, name, None)
+    if fn is not None:
+        setattr(fn, field, value)
+
+
 def load_library(path: str | None = None) -> C.CDLL:
     """Load librt_amd.so and declare prototypes.  Raises if the library is absent."""
     global _lib
@@ -106,69 +114,69 @@ def load_library(path: str | None = None) -> C.CDLL:
         )
     lib = C.CDLL(p)
     vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
-    lib.rt_version.restype = C.c_int
-    lib.rt_rng4.argtypes = [u32, u32, u32, u32, C.POINTER(u32)]
-    lib.rt_rng4.restype = None
-    lib.rt_rng4_device_host.argtypes = [vp, C.c_int, vp, vp]
-    lib.rt_rng4_device_host.restype = C.c_int
-    lib.rt_output_rows.argtypes = [C.POINTER(_Params)]
-    lib.rt_output_rows.restype = C.c_int
-    lib.rt_create.argtypes = [C.c_int, C.POINTER(vp)]
-    lib.rt_create.restype = C.c_int
-    lib.rt_destroy.argtypes = [vp]
-    lib.rt_destroy.restype = None
-    lib.rt_last_error.argtypes = [vp]
-    lib.rt_last_error.restype = C.c_char_p
-    lib.rt_upload_scene.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
-    lib.rt_upload_scene.restype = C.c_int
-    lib.rt_upload_scene_ex.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
-    lib.rt_upload_scene_ex.restype = C.c_int
-    lib.rt_upload_lights.argtypes = [vp, C.c_int, vp]
-    lib.rt_upload_lights.restype = C.c_int
-    lib.rt_set_camera.argtypes = [vp, vp]
-    lib.rt_set_camera.restype = C.c_int
-    lib.rt_render.argtypes = [vp, C.POINTER(_Params), vp, vp, vp, vp]
-    lib.rt_render.restype = C.c_int
-    lib.rt_render_noalloc.argtypes = [vp, C.POINTER(_Params), vp, vp, vp, vp]
-    lib.rt_render_noalloc.restype = C.c_int
-    lib.rt_render_host.argtypes = [vp, C.POINTER(_Params), vp, vp, C.POINTER(C.c_uint64)]
-    lib.rt_render_host.restype = C.c_int
-    lib.rt_last_kernel_ms.argtypes = [vp]
-    lib.rt_last_kernel_ms.restype = C.c_float
-    lib.rt_device_allocations.argtypes = [vp]
-    lib.rt_device_allocations.restype = C.c_uint64
-    lib.rt_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
-    lib.rt_group_create.restype = C.c_int
-    lib.rt_group_destroy.argtypes = [vp]
-    lib.rt_group_destroy.restype = None
-    lib.rt_group_last_error.argtypes = [vp]
-    lib.rt_group_last_error.restype = C.c_char_p
-    lib.rt_group_size.argtypes = [vp]
-    lib.rt_group_size.restype = C.c_int
-    lib.rt_group_transport.argtypes = [vp]
-    lib.rt_group_transport.restype = C.c_char_p
-    lib.rt_group_device_allocations.argtypes = [vp]
-    lib.rt_group_device_allocations.restype = C.c_uint64
-    lib.rt_group_upload_scene_ex.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
-    lib.rt_group_upload_scene_ex.restype = C.c_int
-    lib.rt_group_upload_lights.argtypes = [vp, C.c_int, vp]
-    lib.rt_group_upload_lights.restype = C.c_int
-    lib.rt_group_set_camera.argtypes = [vp, vp]
-    lib.rt_group_set_camera.restype = C.c_int
-    lib.rt_group_render.argtypes = [vp, C.POINTER(_Params), C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(_GroupTiming)]
-    lib.rt_group_render.restype = C.c_int
-    lib.rt_group_render_host.argtypes = [vp, C.POINTER(_Params), vp, C.POINTER(C.c_uint64), C.POINTER(_GroupTiming)]
-    lib.rt_group_render_host.restype = C.c_int
-    lib.rt_first_hit.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp]
-    lib.rt_first_hit.restype = C.c_int
-    lib.rt_first_hit_host.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp]
-    lib.rt_first_hit_host.restype = C.c_int
-    lib.rt_first_hit_ex.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp, vp]
-    lib.rt_first_hit_ex.restype = C.c_int
-    lib.rt_first_hit_ex_host.argtypes = [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp]
-    lib.rt_first_hit_ex_host.restype = C.c_int
-    lib.rt_scatter_host.argtypes = [vp, C.c_int] + [vp] * 10
-    lib.rt_scatter_host.restype = C.c_int
+    _proto(lib, "rt_version", "restype", C.c_int)
+    _proto(lib, "rt_rng4", "argtypes", [u32, u32, u32, u32, C.POINTER(u32)])
+    _proto(lib, "rt_rng4", "restype", None)
+    _proto(lib, "rt_rng4_device_host", "argtypes", [vp, C.c_int, vp, vp])
+    _proto(lib, "rt_rng4_device_host", "restype", C.c_int)
+    _proto(lib, "rt_output_rows", "argtypes", [C.POINTER(_Params)])
+    _proto(lib, "rt_output_rows", "restype", C.c_int)
+    _proto(lib, "rt_create", "argtypes", [C.c_int, C.POINTER(vp)])
+    _proto(lib, "rt_create", "restype", C.c_int)
+    _proto(lib, "rt_destroy", "argtypes", [vp])
+    _proto(lib, "rt_destroy", "restype", None)
+    _proto(lib, "rt_last_error", "argtypes", [vp])
+    _proto(lib, "rt_last_error", "restype", C.c_char_p)
+    _proto(lib, "rt_upload_scene", "argtypes", [vp, C.c_int, vp, vp, C.c_int, vp])
+    _proto(lib, "rt_upload_scene", "restype", C.c_int)
+    _proto(lib, "rt_upload_scene_ex", "argtypes", [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp])
+    _proto(lib, "rt_upload_scene_ex", "restype", C.c_int)
+    _proto(lib, "rt_upload_lights", "argtypes", [vp, C.c_int, vp])
+    _proto(lib, "rt_upload_lights", "restype", C.c_int)
+    _proto(lib, "rt_set_camera", "argtypes", [vp, vp])
+    _proto(lib, "rt_set_camera", "restype", C.c_int)
+    _proto(lib, "rt_render", "argtypes", [vp, C.POINTER(_Params), vp, vp, vp, vp])
+    _proto(lib, "rt_render", "restype", C.c_int)
+    _proto(lib, "rt_render_noalloc", "argtypes", [vp, C.POINTER(_Params), vp, vp, vp, vp])
+    _proto(lib, "rt_render_noalloc", "restype", C.c_int)
+    _proto(lib, "rt_render_host", "argtypes", [vp, C.POINTER(_Params), vp, vp, C.POINTER(C.c_uint64)])
+    _proto(lib, "rt_render_host", "restype", C.c_int)
+    _proto(lib, "rt_last_kernel_ms", "argtypes", [vp])
+    _proto(lib, "rt_last_kernel_ms", "restype", C.c_float)
+    _proto(lib, "rt_device_allocations", "argtypes", [vp])
+    _proto(lib, "rt_device_allocations", "restype", C.c_uint64)
+    _proto(lib, "rt_group_create", "argtypes", [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)])
+    _proto(lib, "rt_group_create", "restype", C.c_int)
+    _proto(lib, "rt_group_destroy", "argtypes", [vp])
+    _proto(lib, "rt_group_destroy", "restype", None)
+    _proto(lib, "rt_group_last_error", "argtypes", [vp])
+    _proto(lib, "rt_group_last_error", "restype", C.c_char_p)
+    _proto(lib, "rt_group_size", "argtypes", [vp])
+    _proto(lib, "rt_group_size", "restype", C.c_int)
+    _proto(lib, "rt_group_transport", "argtypes", [vp])
+    _proto(lib, "rt_group_transport", "restype", C.c_char_p)
+    _proto(lib, "rt_group_device_allocations", "argtypes", [vp])
+    _proto(lib, "rt_group_device_allocations", "restype", C.c_uint64)
+    _proto(lib, "rt_group_upload_scene_ex", "argtypes", [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp])
+    _proto(lib, "rt_group_upload_scene_ex", "restype", C.c_int)
+    _proto(lib, "rt_group_upload_lights", "argtypes", [vp, C.c_int, vp])
+    _proto(lib, "rt_group_upload_lights", "restype", C.c_int)
+    _proto(lib, "rt_group_set_camera", "argtypes", [vp, vp])
+    _proto(lib, "rt_group_set_camera", "restype", C.c_int)
+    _proto(lib, "rt_group_render", "argtypes", [vp, C.POINTER(_Params), C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(_GroupTiming)])
+    _proto(lib, "rt_group_render", "restype", C.c_int)
+    _proto(lib, "rt_group_render_host", "argtypes", [vp, C.POINTER(_Params), vp, C.POINTER(C.c_uint64), C.POINTER(_GroupTiming)])
+    _proto(lib, "rt_group_render_host", "restype", C.c_int)
+    _proto(lib, "rt_first_hit", "argtypes", [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp])
+    _proto(lib, "rt_first_hit", "restype", C.c_int)
+    _proto(lib, "rt_first_hit_host", "argtypes", [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp])
+    _proto(lib, "rt_first_hit_host", "restype", C.c_int)
+    _proto(lib, "rt_first_hit_ex", "argtypes", [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp, vp])
+    _proto(lib, "rt_first_hit_ex", "restype", C.c_int)
+    _proto(lib, "rt_first_hit_ex_host", "argtypes", [vp, C.c_int, vp, vp, C.c_float, u32, vp, vp, vp, vp, vp])
+    _proto(lib, "rt_first_hit_ex_host", "restype", C.c_int)
+    _proto(lib, "rt_scatter_host", "argtypes", [vp, C.c_int] + [vp] * 10)
+    _proto(lib, "rt_scatter_host", "restype", C.c_int)
     if path is None:
         _lib = lib
     return lib

@@ -38,6 +38,7 @@ constexpr int WG_THREADS = 256;
 constexpr int WAVES_PER_WG = 4;
 constexpr int MAX_TILE_PX = 64;              // largest pixel tile a work item may cover (8 x 8)
 constexpr int RESIDENT_MAX = 4096;           // spheres kept resident in LDS (80 KiB)
+constexpr int SMALL_SCENE = 8;               // up to this many spheres the scalar-load scan decides every sphere directly
 constexpr int STREAM_QUADS = 512;            // quads (4 spheres, 80 B) per streamed LDS tile (40 KiB)
 constexpr int SLOT_WORDS = 3 * MAX_TILE_PX;  // one tile slot's accumulators: r, g, b planes of 64-bit sums
 constexpr int WAVE_LDS_WORDS = 2 * SLOT_WORDS + 8; // two slots and their tile descriptors
@@ -75,6 +76,7 @@ struct KParams {
     int tiles_per_strip; // tiles_x * (8 / tile height)
     int n_items;         // tiles this call renders
     int n_quads;     // sphere quads to scan (padding included)
+    int n_spheres;   // spheres of the scene
     int n_lights;    // lights shaded at every hit (0 unless RT_FLAG_DIRECT_LIGHT)
     float inv_w, inv_h;
     float cam[12];   // center, upper_left, right, down
@@ -128,22 +130,31 @@ __device__ __forceinline__ float4 word(const u32x16 &v, int k) {
 }
 // nquads is even (the list is padded with never-hit spheres) and four spare quads follow
 // it, so the read-ahead never leaves the arrays.  Two quads are requested while two are
-// tested; a list of two quads is one request and one wait.
+// tested.
 // Called by the whole wave, lanes without a ray included (their threshold is +inf): what passes
 // the filter is queued and decided in full batches (rt_device.h), which needs every lane.
 __device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, int nquads, const RayK &r, V3 o, V3 dh,
                                             float tmin, int self_id, int lane, const CandQ &cq,
-                                            const float4 *__restrict__ sph, float &best_t, int &best_id) {
+                                            const float4 *__restrict__ sph, int n_spheres, float &best_t,
+                                            int &best_id) {
+    if (n_spheres <= SMALL_SCENE) {
+        // a handful of spheres: every lane decides every sphere outright, in insertion order with the
+        // shrinking interval of hitClosest.  Filter, queue and batches would cost more than they save,
+        // and the result is the same: the filter only ever drops spheres this decision rejects.
+        for (int i = 0; i < n_spheres; ++i) {
+            const float4 sp = sph[i]; // same address in every lane: a scalar load
+            const float cand = sphere_root(o, dh, sp.x, sp.y, sp.z, sp.w * sp.w, tmin);
+            if (cand > tmin && cand < best_t && i != self_id) {
+                best_t = cand;
+                best_id = i;
+            }
+        }
+        return;
+    }
     cq.slot[lane] = NO_HIT_KEY;
     int count = 0; // queue fill, wave-uniform
     u32x16 A0 = sload_quad<0>(g), A1 = sload_quad<64>(g);
     __builtin_amdgcn_sched_barrier(0);
-    if (nquads <= 2) {
-        swait_quads(A0, A1);
-        queue_quad2(r, word(A0, 0), word(A0, 1), word(A0, 2), word(A0, 3), word(A1, 0), word(A1, 1), word(A1, 2),
-                    word(A1, 3), 0, lane, cq, count, o, dh, tmin, self_id, sph);
-        nquads = 0; // skips the loop below
-    }
 #pragma unroll 1
     for (int q = 0; q < nquads; q += 4) {
         swait_quads(A0, A1);
@@ -277,6 +288,21 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
     }
     __syncthreads();
 
+#ifdef RT_SECTIONS
+    // tuning build: shader cycles this wave spends in each part of the loop body
+    unsigned long long sec_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long sec_last = __builtin_amdgcn_s_memtime();
+    int sec_cur = 7;
+#define RT_SEC(k)                                                     \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        sec_t[sec_cur] += now_ - sec_last;                            \
+        sec_last = now_;                                              \
+        sec_cur = (k);                                                \
+    } while (0)
+#else
+#define RT_SEC(k)
+#endif
 #ifdef RT_STATS
     const unsigned long long t_start = wall_clock64();
     unsigned long long t_fetch[2] = {t_start, t_start};
@@ -319,6 +345,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
             if (!wave_live) break;
         }
 
+        RT_SEC(0); // ray set-up and the scan
         const bool in_shadow = FULL && ls.light_i >= 0;
         const bool active = pt.pix >= 0 && (pt.depth > 0 || in_shadow);
         // a path with no depth left (max_depth == 0) contributes black and ends at once
@@ -353,10 +380,11 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         } else {
             // the whole wave scans: a lane without a ray passes no filter
             rk.thr = active ? rk.thr : __builtin_inff();
-            scan_scalar(sc.pairs, nquads, rk, pt.o, pt.dh, tmin, pt.self_id, lane, cq, sc.sph, best_t, best_id);
+            scan_scalar(sc.pairs, nquads, rk, pt.o, pt.dh, tmin, pt.self_id, lane, cq, sc.sph, p.n_spheres, best_t, best_id);
         }
 
         // ---- shade (Camera::getRayColor, src/Camera.cpp:137-157) ----
+        RT_SEC(1);
         bool bounce = false;
         Hit h;
         h.p = h.n = mk(0, 0, 0);
@@ -456,6 +484,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                 }
             }
         }
+        RT_SEC(2); // radiance of finished paths into the tile's sums
         if (finished) {
             atomicAdd(&acc[pt.pix], to_fixed(pt.L.x));
             atomicAdd(&acc[MAX_TILE_PX + pt.pix], to_fixed(pt.L.y));
@@ -465,6 +494,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
 
         // ---- a slot whose pool has run dry and whose last path has ended: tone-map and store
         //      (convertRTColor, src/Camera.cpp:19-34) ----
+        RT_SEC(3); // tiles that are done: tone-map and store
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bool occupied = s ? have1 : have0;
@@ -506,6 +536,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         // ---- hand the next (pixel, sample) of the open pool to every lane without a path
         //      (ballot + prefix count); when the pool runs dry, open the next tile's in the free
         //      slot and go on, so the wave stays full until the queue is empty ----
+        RT_SEC(4); // hand-out of new samples
         bool fresh = false;
         int px = 0, py = 0;
         for (unsigned long long m = __ballot(pt.pix < 0); m != 0; m = __ballot(pt.pix < 0)) {
@@ -578,6 +609,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
 
         // ---- the next ray of every lane that has one to make: a primary ray (Camera::genRay,
         //      src/Camera.cpp:124-135) or a bounce (RTMaterial::scatter); one random draw serves both ----
+        RT_SEC(5); // random words, primary ray or scatter
         if (fresh || bounce) {
             uint32_t w0, w1, w2, w3;
             rng4(pt.gpix, pt.sample, pt.call, p.seed, w0, w1, w2, w3);
@@ -615,6 +647,11 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         }
 
     }
+#ifdef RT_SECTIONS
+    RT_SEC(7);
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_sections[k], sec_t[k]);
+#endif
 #ifdef RT_STATS
     if (lane == 0 && items_done > 0) {
         const unsigned long long t_end = wall_clock64();
@@ -1160,6 +1197,16 @@ int local_strips(const rt_params *p) {
 
 } // namespace
 
+#ifdef RT_SECTIONS
+extern "C" __attribute__((visibility("default"))) int rt_debug_sections(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sections), sizeof(g_sections)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_sections), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 #ifdef RT_STATS
 extern "C" __attribute__((visibility("default"))) int rt_debug_stats(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(g_stats)) != hipSuccess) return -1;
@@ -1497,6 +1544,7 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
     k.tiles_x = (p->width + tw - 1) / tw;
     k.tiles_per_strip = k.tiles_x * (RT_STRIP_ROWS / th);
     k.n_quads = ctx->n_quads;
+    k.n_spheres = ctx->n_spheres;
     k.n_lights = (p->flags & RT_FLAG_DIRECT_LIGHT) ? ctx->n_lights : 0;
     k.inv_w = 1.0f / (float)p->width;
     k.inv_h = 1.0f / (float)p->height;

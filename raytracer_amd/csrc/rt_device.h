@@ -121,6 +121,9 @@ __device__ __forceinline__ f2 pair_filter(const RayK &r, float4 A, float4 B) {
     return __builtin_elementwise_fma(cz, r.kz, __builtin_elementwise_fma(cy, r.ky, __builtin_elementwise_fma(cx, r.kx, t)));
 }
 
+#ifdef RT_SECTIONS
+__device__ unsigned long long g_sections[8]; // tuning build only: wave cycles per part of the render loop
+#endif
 #ifdef RT_STATS
 // tuning build only: wave-level event counters
 __device__ unsigned long long g_stats[8];
