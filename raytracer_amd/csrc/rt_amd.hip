@@ -52,11 +52,25 @@ constexpr size_t WAVE_STATE_BYTES = ACC_BYTES + CQ_BYTES;
 // shares the wave, i.e. with timing -- and a frame renders to the same bytes every time and
 // under every strip partition.  One sample is clamped to +-2^30 (a NaN counts as 0) and
 // resolved to 2^-24; the sum holds 2^39, i.e. 2^26 samples of average radiance 8192.
-__device__ __forceinline__ unsigned long long to_fixed(float x) {
-    float m = fminf(fmaxf(fabsf(x), 0.0f), 1073741824.0f);
-    float hi = floorf(m);
-    long long v = (long long)(((unsigned long long)(unsigned)hi << 24) | (unsigned long long)(unsigned)((m - hi) * 16777216.0f));
-    return (unsigned long long)(x < 0.0f ? -v : v);
+// |x| in 40.24 fixed point.  For m >= 0 the conversion to unsigned truncates like floor, and
+// v_fract_f32 returns m - floor(m) exactly.
+__device__ __forceinline__ unsigned long long to_fixed_magnitude(float x) {
+    const float m = fminf(fmaxf(fabsf(x), 0.0f), 1073741824.0f);
+    const unsigned hi = (unsigned)m;
+    const unsigned lo = (unsigned)(__builtin_amdgcn_fractf(m) * 16777216.0f);
+    return ((unsigned long long)hi << 24) | (unsigned long long)lo;
+}
+// The three channels of one sample.  Radiance is hardly ever negative (it takes a negative emission or
+// albedo), so the sign is applied on a path of its own that a wave enters only if one of its lanes needs it.
+__device__ __forceinline__ void to_fixed3(V3 L, unsigned long long &fx, unsigned long long &fy, unsigned long long &fz) {
+    fx = to_fixed_magnitude(L.x);
+    fy = to_fixed_magnitude(L.y);
+    fz = to_fixed_magnitude(L.z);
+    if (__ballot(fminf(fminf(L.x, L.y), L.z) < 0.0f)) {
+        fx = L.x < 0.0f ? 0ull - fx : fx;
+        fy = L.y < 0.0f ? 0ull - fy : fy;
+        fz = L.z < 0.0f ? 0ull - fz : fz;
+    }
 }
 __device__ __forceinline__ float from_fixed(unsigned long long v) {
     return (float)((double)(long long)v * (1.0 / 16777216.0));
@@ -88,6 +102,7 @@ struct DeviceScene {
                           // never-hit spheres to a multiple of 8 plus four spare quads
     const float4 *r2q;    // squared radii, one float4 per group of four spheres, padded alike
     const uint32_t *mat_id;
+    const DMat *sph_mats; // the material of every sphere, by sphere index: one load instead of two dependent ones
     const DMat *mats;
     const DLight *lights;
     FullScene full; // general primitive list (used by the FULL kernel variants only)
@@ -201,9 +216,11 @@ struct Path {
     V3 dh;        // d / |d|
     float len, inv_len; // |d| and its reciprocal
     int pix;      // pixel index inside the wave tile, -1 = lane has no work
-    uint32_t gpix; // global pixel id (RNG key)
+    // RNG key words, each already through rng_key(): global pixel id, sample index, and call index
+    // (0 = ray generation, k = k-th bounce; the next call's word is this one plus RNG_MUL)
+    uint32_t gpix;
     uint32_t sample;
-    uint32_t call; // RNG call index: 0 = ray generation, k = k-th bounce
+    uint32_t call;
     int depth;    // closest-hit queries left
     int self_id;  // sphere whose surface the ray starts on exactly (diffuse / metal bounce), else -1
 };
@@ -431,9 +448,8 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                         halo = c.expanded;
                     } else {
                         h = finish_hit(pt.o, pt.d, best_t * pt.inv_len, sc.sph[best_id]);
-                        hit_mat = (int)sc.mat_id[best_id];
                     }
-                    const DMat &m = sc.mats[hit_mat];
+                    const DMat &m = FULL ? sc.mats[hit_mat] : sc.sph_mats[best_id];
                     at = m.albedo_type;
                     ef = m.emission_fuzz;
                     ior = m.ior_diffuse.x;
@@ -486,9 +502,11 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         }
         RT_SEC(2); // radiance of finished paths into the tile's sums
         if (finished) {
-            atomicAdd(&acc[pt.pix], to_fixed(pt.L.x));
-            atomicAdd(&acc[MAX_TILE_PX + pt.pix], to_fixed(pt.L.y));
-            atomicAdd(&acc[2 * MAX_TILE_PX + pt.pix], to_fixed(pt.L.z));
+            unsigned long long fx, fy, fz;
+            to_fixed3(pt.L, fx, fy, fz);
+            atomicAdd(&acc[pt.pix], fx);
+            atomicAdd(&acc[MAX_TILE_PX + pt.pix], fy);
+            atomicAdd(&acc[2 * MAX_TILE_PX + pt.pix], fz);
             pt.pix = -1;
         }
 
@@ -588,9 +606,9 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                     pt.pix = fill * SLOT_WORDS + (ly << p.tile_w_log2) + lx;
                     px = tile.x0 + lx;
                     py = tile.y0 + ly;
-                    pt.gpix = (uint32_t)(py * p.width + px);
-                    pt.sample = (uint32_t)(smp + p.sample_offset);
-                    pt.call = 0;
+                    pt.gpix = rng_key((uint32_t)(py * p.width + px));
+                    pt.sample = rng_key((uint32_t)(smp + p.sample_offset));
+                    pt.call = rng_key(0u);
                     pt.T = mk(1, 1, 1);
                     pt.L = mk(0, 0, 0);
                     pt.depth = p.max_depth;
@@ -612,8 +630,8 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         RT_SEC(5); // random words, primary ray or scatter
         if (fresh || bounce) {
             uint32_t w0, w1, w2, w3;
-            rng4(pt.gpix, pt.sample, pt.call, p.seed, w0, w1, w2, w3);
-            pt.call++;
+            rng4_keyed(pt.gpix, pt.sample, pt.call, rng_key(p.seed), w0, w1, w2, w3);
+            pt.call += RNG_MUL;
             V3 nd;
             if (fresh) {
                 gen_ray(p, px, py, u01(w0), u01(w1), pt.o, nd);
@@ -1104,6 +1122,7 @@ struct rt_ctx {
     int force_tile = -1; // tuning: 0 = 1x1, 1 = 2x2, 2 = 4x4, 3 = 8x8 work-item tiles
     uint32_t *d_mat_id = nullptr;
     DMat *d_mats = nullptr;
+    DMat *d_sph_mats = nullptr;
     DLight *d_lights = nullptr;
     int n_lights = 0;
     // the general primitive list (every scene has one; sphere-only scenes only use it with lights)
@@ -1317,6 +1336,7 @@ DeviceScene device_scene(const rt_ctx *ctx) {
     sc.r2q = ctx->d_r2q;
     sc.mat_id = ctx->d_mat_id;
     sc.mats = ctx->d_mats;
+    sc.sph_mats = ctx->d_sph_mats;
     sc.lights = ctx->d_lights;
     sc.full.prims = ctx->d_prims;
     sc.full.verts = ctx->d_verts;
@@ -1425,12 +1445,15 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
         mats.push_back(m);
     }
     std::vector<float> verts(h_vertices, h_vertices + 3 * (size_t)n_vertices);
+    std::vector<DMat> sph_mats(mid.size());
+    for (size_t i = 0; i < mid.size(); ++i) sph_mats[i] = mats[mid[i]];
     int rc;
     if ((rc = to_device(ctx, &ctx->d_sph, sph)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_pairs, pairs)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_r2q, r2q)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_mat_id, mid)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_mats, mats)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, &ctx->d_sph_mats, sph_mats)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_prims, prims)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_verts, verts)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_others, others)) != RT_OK) return rc;

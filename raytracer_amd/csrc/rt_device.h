@@ -41,12 +41,26 @@ struct DLight {
 // pcg4d (Jarzynski & Olano, JCGT 2020) keyed on (pixel, sample, call, seed): one
 // evaluation yields the four words a bounce can consume.  Stands in for the
 // per-thread generator the reference seeds per pixel (src/Camera.cpp:84).
+constexpr uint32_t RNG_MUL = 1664525u, RNG_ADD = 1013904223u;
+// first step of the generator: a key word through one linear congruential step.  A path keeps its
+// pixel and sample words in this form, and its call word too: the next call's is this plus RNG_MUL.
+__host__ __device__ __forceinline__ uint32_t rng_key(uint32_t v) { return v * RNG_MUL + RNG_ADD; }
+
+// the mixing rounds on key words that have been through rng_key()
+__host__ __device__ __forceinline__ void rng4_keyed(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t &o0,
+                                                    uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    o0 = x; o1 = y; o2 = z; o3 = w;
+}
+
 __host__ __device__ __forceinline__ void rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed,
                                               uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
-    uint32_t x = pixel * 1664525u + 1013904223u;
-    uint32_t y = sample * 1664525u + 1013904223u;
-    uint32_t z = call * 1664525u + 1013904223u;
-    uint32_t w = seed * 1664525u + 1013904223u;
+    uint32_t x = rng_key(pixel);
+    uint32_t y = rng_key(sample);
+    uint32_t z = rng_key(call);
+    uint32_t w = rng_key(seed);
     x += y * w; y += z * x; z += x * y; w += y * z;
     x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
     x += y * w; y += z * x; z += x * y; w += y * z;
@@ -417,17 +431,20 @@ __device__ __forceinline__ float reflectance(float cosine, float ri) {
 __device__ __forceinline__ bool scatter(uint32_t type, V3 albedo, float fuzz, float ior, V3 d_in, const Hit &h,
                                         float u0, float u1, float u2, V3 &att, V3 &o_out, V3 &d_out) {
     att = albedo;
-    if (type == 0u) { // Lambertian: normal + random unit vector, not normalised
-        V3 dir = h.n + random_unit(u0, u1);
-        if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = h.n;
+    if (type <= 1u) {
+        // Lambertian: normal + random unit vector, not normalised (:67-80).  Metal: always scatters, even
+        // below the surface: normalised mirror direction + fuzz * random unit vector (:105-115).
+        // One form serves both, so a wave that holds both kinds runs it once: base + spread * unit.
+        V3 base = h.n;
+        float spread = 1.0f;
+        if (type == 1u) {
+            base = normalized(reflect(d_in, h.n));
+            spread = fuzz;
+        }
+        V3 dir = madd(base, random_unit(u0, u1), spread);
+        if (type == 0u && fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = h.n;
         o_out = h.p;
         d_out = dir;
-        return true;
-    }
-    if (type == 1u) { // Metal: always scatters, even below the surface
-        V3 r = reflect(d_in, h.n);
-        d_out = madd(normalized(r), random_unit(u0, u1), fuzz);
-        o_out = h.p;
         return true;
     }
     if (type == 2u) { // Dielectric
