@@ -156,8 +156,9 @@ __device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, int nq
         // a handful of spheres: every lane decides every sphere outright, in insertion order with the
         // shrinking interval of hitClosest.  Filter, queue and batches would cost more than they save,
         // and the result is the same: the filter only ever drops spheres this decision rejects.
+        const cptr<float4> csph = as_const(sph);
         for (int i = 0; i < n_spheres; ++i) {
-            const float4 sp = sph[i]; // same address in every lane: a scalar load
+            const float4 sp = load_const4(csph, i); // same address in every lane: a scalar load
             const float cand = sphere_root(o, dh, sp.x, sp.y, sp.z, sp.w * sp.w, tmin);
             if (cand > tmin && cand < best_t && i != self_id) {
                 best_t = cand;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                 } else {
                     if (FULL) {
                         h = finish_any(sc.full, pt.o, pt.d, c, hit_obj);
-                        const DPrim &pr = sc.full.prims[c.prim];
+                        const DPrim pr = load_prim(sc.full.prims, c.prim);
                         hit_mat = (int)pr.mat;
                         hit_self = (pr.type == PRIM_SPHERE && c.scale == 1.0f) ? pr.sph_local : -1;
                         halo = c.expanded;
@@ -757,7 +758,7 @@ __device__ __forceinline__ void face64(Rec64 &rec, D3 d, D3 outward) {
 
 __device__ __noinline__ bool prim_hit64(const FullScene &fs, int idx, D3 o, D3 d, double tmin, double tmax, double scale,
                                         Rec64 &rec) {
-    const DPrim &pr = fs.prims[idx];
+    const DPrim pr = load_prim(fs.prims, idx);
     if (pr.type == PRIM_SPHERE) {
         double r = (double)pr.p[3] * scale, t;
         if (!hit64(o.x, o.y, o.z, d.x, d.y, d.z, tmin, tmax, pr.p[0], pr.p[1], pr.p[2], r, t)) return false;
@@ -832,7 +833,7 @@ __device__ __noinline__ bool prim_hit64(const FullScene &fs, int idx, D3 o, D3 d
             else { u = q.x; v = q.y; }
         };
         auto vertex = [&](int k) {
-            const float *vv = fs.verts + 3 * ((size_t)pr.first_vertex + (size_t)k);
+            cptr<float> vv = fs.verts + 3 * ((size_t)pr.first_vertex + (size_t)k);
             D3 v = d3(vv[0], vv[1], vv[2]);
             if (scale != 1.0) {
                 D3 sd = d3((v.x - cen.x) * scale, (v.y - cen.y) * scale, (v.z - cen.z) * scale);
@@ -1338,11 +1339,11 @@ DeviceScene device_scene(const rt_ctx *ctx) {
     sc.mats = ctx->d_mats;
     sc.sph_mats = ctx->d_sph_mats;
     sc.lights = ctx->d_lights;
-    sc.full.prims = ctx->d_prims;
-    sc.full.verts = ctx->d_verts;
-    sc.full.others = ctx->d_others;
-    sc.full.halo = ctx->d_halo;
-    sc.full.sph_gid = ctx->d_sph_gid;
+    sc.full.prims = as_const(ctx->d_prims);
+    sc.full.verts = as_const(ctx->d_verts);
+    sc.full.others = as_const(ctx->d_others);
+    sc.full.halo = as_const(ctx->d_halo);
+    sc.full.sph_gid = as_const(ctx->d_sph_gid);
     sc.full.n_others = ctx->n_others;
     sc.full.n_halo = ctx->n_halo;
     return sc;

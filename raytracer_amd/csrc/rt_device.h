@@ -23,6 +23,26 @@ __host__ __device__ __forceinline__ V3 madd(V3 a, V3 b, float s) {
 }
 __device__ __forceinline__ V3 normalized(V3 a) { return a * __frsqrt_rn(dot(a, a)); }
 
+// Scene data never changes while a kernel runs.  Reading it through the constant address space tells
+// the compiler so: wherever the address is the same in every lane (loops over the primitive list, the
+// lights, a small sphere list) it then uses scalar loads, which return into SGPRs through the scalar
+// cache and cost neither vector registers nor vector-memory latency.
+template <class T>
+using cptr = const T __attribute__((address_space(4))) *;
+template <class T>
+__host__ __device__ __forceinline__ cptr<T> as_const(const T *p) {
+    return (cptr<T>)(uintptr_t)p;
+}
+
+typedef float cfloat4 __attribute__((ext_vector_type(4)));
+typedef uint32_t cuint4 __attribute__((ext_vector_type(4)));
+// float4 number i of a constant array (class types cannot be copied out of another address space; the
+// compiler's own vector types can)
+__device__ __forceinline__ float4 load_const4(cptr<float4> p, int i) {
+    const cfloat4 v = ((cptr<cfloat4>)p)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // Device copy of one material: three 16-byte words.
 struct DMat {
     float4 albedo_type; // albedo rgb, type in the bits of .w
@@ -478,7 +498,7 @@ __device__ __forceinline__ bool scatter(uint32_t type, V3 albedo, float fuzz, fl
 // Light::getDirectLighting with its Lambert and Phong terms (inc/RTObjects.h:247-257, 300-320):
 // ambient*diffuse_ + (max(0, cos)*defuse*diffuse_ + pow(max(0, cos(mirror(toLight), toView)), pow)) * shadow.
 // toLight - 2*getOrtogonal(toLight, n) is toLight mirrored about the (unit) normal.
-__device__ __forceinline__ V3 light_direct(const DLight &lt, V3 cam_center, V3 p, V3 n, V3 mdiff, bool hitted) {
+__device__ __forceinline__ V3 light_direct(const DLight lt, V3 cam_center, V3 p, V3 n, V3 mdiff, bool hitted) {
     V3 to_light = normalized(mk(lt.pos_pow.x, lt.pos_pow.y, lt.pos_pow.z) - p);
     V3 to_view = normalized(cam_center - p);
     V3 out = mk(lt.ambient.x, lt.ambient.y, lt.ambient.z) * mdiff;

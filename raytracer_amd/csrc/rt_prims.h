@@ -25,12 +25,28 @@ struct DPrim {
     uint32_t _pad[2];
 };
 
+static_assert(sizeof(DPrim) == 64, "load_prim reads a primitive as four 16-byte words");
+
+// One record of a constant primitive list (64 bytes: one s_load_dwordx16 when the index is uniform).
+__device__ __forceinline__ DPrim load_prim(cptr<DPrim> list, int idx) {
+    cptr<cuint4> w = (cptr<cuint4>)(list + idx);
+    const cuint4 a = w[0], b = w[1], c = w[2], d = w[3];
+    DPrim r;
+    r.type = a.x; r.mat = a.y; r.first_vertex = a.z; r.n_vertices = a.w;
+    r.p[0] = __uint_as_float(b.x); r.p[1] = __uint_as_float(b.y); r.p[2] = __uint_as_float(b.z); r.p[3] = __uint_as_float(b.w);
+    r.p[4] = __uint_as_float(c.x); r.p[5] = __uint_as_float(c.y); r.p[6] = __uint_as_float(c.z); r.p[7] = __uint_as_float(c.w);
+    r.selected = d.x; r.sph_local = (int32_t)d.y; r._pad[0] = d.z; r._pad[1] = d.w;
+    return r;
+}
+
 struct FullScene {
-    const DPrim *prims;        // every primitive, in insertion order
-    const float *verts;        // polygon vertices, xyz
-    const int32_t *others;     // indices of the non-sphere primitives, ascending
-    const int32_t *halo;       // indices taking part in the halo pass (selected ones and planes), ascending
-    const int32_t *sph_gid;    // packed sphere index -> primitive index
+    // read through the constant address space: loops over these lists run the same index in every lane
+    // and get scalar loads
+    cptr<DPrim> prims;        // every primitive, in insertion order
+    cptr<float> verts;        // polygon vertices, xyz
+    cptr<int32_t> others;     // indices of the non-sphere primitives, ascending
+    cptr<int32_t> halo;       // indices taking part in the halo pass (selected ones and planes), ascending
+    cptr<int32_t> sph_gid;    // packed sphere index -> primitive index
     int n_others, n_halo;
 };
 
@@ -116,7 +132,7 @@ __device__ __forceinline__ void project2d(V3 n, V3 p, float &u, float &v) {
 
 // PolygonObject::hitDetail + pointInPolygon2D, inc/RTObjects.h:455-497; `scale` pushes the vertices
 // away from the centroid for the halo (:375-381).
-__device__ __forceinline__ bool polygon_t(V3 o, V3 d, float tmin, float tmax, const DPrim &pr, const float *verts,
+__device__ __forceinline__ bool polygon_t(V3 o, V3 d, float tmin, float tmax, const DPrim &pr, cptr<float> verts,
                                           float scale, float &t) {
     const int nv = (int)pr.n_vertices;
     if (nv < 3) return false;
@@ -129,7 +145,7 @@ __device__ __forceinline__ bool polygon_t(V3 o, V3 d, float tmin, float tmax, co
     float px, py;
     project2d(n, p, px, py);
     bool inside = false;
-    const float *vv = verts + 3 * pr.first_vertex;
+    cptr<float> vv = verts + 3 * pr.first_vertex;
     V3 vj = mk(vv[3 * (nv - 1)], vv[3 * (nv - 1) + 1], vv[3 * (nv - 1) + 2]);
     vj = madd(cen, vj - cen, scale);
     for (int i = 0; i < nv; ++i) {
@@ -149,7 +165,7 @@ __device__ __forceinline__ bool polygon_t(V3 o, V3 d, float tmin, float tmax, co
 
 // Primitives::hit of one non-sphere primitive against (tmin, c.t]; updates c on success.
 __device__ __forceinline__ void other_hit(const FullScene &fs, int idx, V3 o, V3 d, float tmin, Closest &c) {
-    const DPrim &pr = fs.prims[idx];
+    const DPrim pr = load_prim(fs.prims, idx);
     float t = 0.f;
     int face = 0;
     bool ok;
@@ -187,7 +203,7 @@ __device__ __forceinline__ Closest halo_pass(const FullScene &fs, V3 o, V3 d, fl
     e.expanded = false;
     for (int k = 0; k < fs.n_halo; ++k) {
         const int idx = fs.halo[k];
-        const DPrim &pr = fs.prims[idx];
+        const DPrim pr = load_prim(fs.prims, idx);
         float t = 0.f;
         int face = 0;
         bool ok = false, grown = false;
@@ -219,7 +235,7 @@ __device__ __forceinline__ Closest halo_pass(const FullScene &fs, V3 o, V3 d, fl
 // Hit point, normal, face flag and HitRecord::object code of the winning primitive
 // (sphere inc/RTObjects.h:151-157, plane :179-187, cube :622-642, polygon :499-507).
 __device__ __forceinline__ Hit finish_any(const FullScene &fs, V3 o, V3 d, const Closest &c, int &object) {
-    const DPrim &pr = fs.prims[c.prim];
+    const DPrim pr = load_prim(fs.prims, c.prim);
     Hit h;
     if (pr.type == PRIM_SPHERE) {
         object = c.prim;

@@ -4,7 +4,8 @@ usage: ab_bytes.py libA.so libB.so"""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [("random_spheres", 320, 180, 40, 50), ("random_spheres", 160, 96, 500, 50), ("small", 256, 144, 64, 50),
-         ("small_bubble", 200, 120, 16, 10), ("grid10k", 128, 72, 8, 50)]
+         ("small_bubble", 200, 120, 16, 10), ("grid10k", 128, 72, 8, 50), ("mixed_selected", 240, 136, 24, 10),
+         ("mixed_lit", 240, 136, 16, 8), ("small_phong", 160, 90, 16, 8), ("halo_overlap", 160, 90, 16, 6)]
 if len(sys.argv) == 4 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
     os.environ["RT_AMD_LIB"] = os.path.abspath(sys.argv[2])
@@ -13,8 +14,10 @@ if len(sys.argv) == 4 and sys.argv[1] == "--child":
     out = {}
     for name, W, H, spp, depth in CASES:
         with Renderer(0) as r:
-            r.set_scene(scenes.by_name(name))
-            rgba, acc, rays = r.render_host(RenderParams(W, H, spp, depth, seed=3), want_accum=True)
+            sc = scenes.by_name(name)
+            r.set_scene(sc)
+            flags = 2 if sc.lights is not None and len(sc.lights) else 0
+            rgba, acc, rays = r.render_host(RenderParams(W, H, spp, depth, seed=3, flags=flags), want_accum=True)
         out[f"{name} {W}x{H} {spp}spp"] = [hashlib.sha256(rgba.tobytes()).hexdigest()[:16],
                                           hashlib.sha256(acc.tobytes()).hexdigest()[:16], rays]
     json.dump(out, open(sys.argv[3], "w"))
