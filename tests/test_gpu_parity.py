@@ -751,21 +751,34 @@ def test_work_distribution_never_changes_a_byte(monkeypatch, scene_name, W, H, s
                 assert total == base_rays
 
 
-def test_general_kernel_with_a_streamed_sphere_list(renderer, oracle64):
-    """Lights on a scene with more spheres than stay resident in LDS: the general kernel streams the sphere
-    list through LDS in tiles shared by the workgroup."""
+@pytest.mark.parametrize("scene_name,W,H,spp,depth", [("grid72", 64, 36, 16, 8), ("random_spheres", 96, 54, 32, 12)])
+def test_general_kernel_with_long_sphere_lists(monkeypatch, oracle64, scene_name, W, H, spp, depth):
+    """Lights on scenes with many spheres (5185: more than stay resident in LDS; 485): the general kernel
+    takes the sphere words through scalar loads and queues candidates like the sphere-only kernel, or, with
+    RT_AMD_SPHERE_SOURCE=lds, from LDS (streamed in tiles shared by the workgroup / resident).  Both
+    render the same bytes, and they match the oracle."""
+    from raytracer_amd import Renderer
     from raytracer_amd.api import FLAG_DIRECT_LIGHT
 
-    scene = scenes.grid_scene(72, 72)  # 5185 spheres
+    scene = scenes.by_name(scene_name)
     scene.lights = scenes.small_scene(phong=1).lights.copy()
     scene.lights["position"][0] = (0.0, 0.0, 30.0)
-    renderer.set_scene(scene)
-    W, H, spp, depth = 64, 36, 16, 8
     p = RenderParams(W, H, samples_per_pixel=spp, max_depth=depth, seed=2, flags=FLAG_DIRECT_LIGHT)
-    rgba, accum, rays = renderer.render_host(p, want_accum=True)
+    out = []
+    for src in ("scalar", "lds"):
+        monkeypatch.setenv("RT_AMD_SPHERE_SOURCE", src)
+        with Renderer(0) as r:
+            r.set_scene(scene)
+            out.append(r.render_host(p, want_accum=True))
+    (rgba, accum, rays), other = out
+    assert np.array_equal(rgba, other[0]) and np.array_equal(accum, other[1]) and rays == other[2]
     ra, acc_a, rays_a = oracle64.render(scene, W, H, spp, depth, seed=2, direct_light=True)
     rb, _, _ = oracle64.render(scene, W, H, spp, depth, seed=3, direct_light=True)
     assert psnr(rgba[:, :, :3], ra[:, :, :3]) >= psnr(ra[:, :, :3], rb[:, :, :3]) - 0.5
+    if scene_name == "random_spheres":
+        # (the glass-heavy grid at 16 spp is chaotic: single precision sends too many of its paths another way
+        # for the same-stream bar; it is held to the seed-to-seed floor above)
+        assert_same_streams(rgba[:, :, :3], ra[:, :, :3], f"{scene_name} + light")
     assert abs(rays - rays_a) <= 0.01 * rays_a
     lin = accum[:, :, :3].astype(np.float64).mean(axis=(0, 1)) / spp
     assert np.allclose(lin, acc_a.mean(axis=(0, 1)) / spp, rtol=1e-2)
