@@ -76,6 +76,43 @@ def test_noalloc_matches_render_on_two_calls_in_a_row():
             assert g[0][..., :3].any(), "frame is black"
 
 
+def test_renders_in_flight_on_two_streams_do_not_share_a_work_counter():
+    """rt_render is asynchronous on the caller's stream; every launch takes the next of a ring of work
+    counters, so two renders issued back to back on two streams of one context (double-buffered frames)
+    both come out whole.  Same for rt_render_noalloc and its static ring."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    W, H = 256, 144
+    pa = RenderParams(W, H, samples_per_pixel=48, max_depth=50, seed=1)
+    pb = RenderParams(W, H, samples_per_pixel=48, max_depth=50, seed=2)
+    with Renderer(0) as r:
+        r.set_scene(scenes.by_name("random_spheres"))
+        want_a, want_b = _render(r, pa, False)[0], _render(r, pb, False)[0]
+        streams = [C.c_void_p(), C.c_void_p()]
+        for st in streams:
+            assert hip.hipStreamCreate(C.byref(st)) == 0
+        for noalloc in (False, True):
+            bufs = [_DevBuf(hip, W * H * 4), _DevBuf(hip, W * H * 4)]
+            for rep in range(3):  # several pairs: the two kernels overlap on the GPU
+                r.render_device(pa, bufs[0], None, None, streams[0].value, noalloc=noalloc)
+                r.render_device(pb, bufs[1], None, None, streams[1].value, noalloc=noalloc)
+            assert hip.hipDeviceSynchronize() == 0
+            got_a = bufs[0].to_numpy(np.uint8, (H, W, 4))
+            got_b = bufs[1].to_numpy(np.uint8, (H, W, 4))
+            assert np.array_equal(got_a, want_a) and np.array_equal(got_b, want_b), f"noalloc={noalloc}"
+            for b in bufs:
+                b.free()
+        for st in streams:
+            hip.hipStreamDestroy(st)
+
+
 def test_noalloc_rejects_what_it_cannot_count():
     from raytracer_amd import RtError
 
