@@ -6,9 +6,11 @@
 //     waves of a persistent grid pull items from one global counter;
 //   * a lane carries one path.  Every iteration all lanes of a wave scan the whole
 //     sphere list (brute force; sphere words arrive through scalar loads, or from LDS in
-//     the general variant), then shade and bounce.  A lane whose path ended adds its
-//     radiance to its tile's fixed-point accumulator in LDS and takes the next
-//     (pixel, sample) of the open pool; indices come from a ballot + prefix count;
+//     the general variant with a short list); spheres that pass the packed filter are
+//     queued per wave and decided 64 at a time with every lane busy; then shade and
+//     bounce.  A lane whose path ended adds its radiance to its tile's fixed-point
+//     accumulator in LDS and takes the next (pixel, sample) of the open pool; indices
+//     come from a ballot + prefix count;
 //   * a wave holds two tiles, so lanes freed near the end of one start on the next at
 //     once; a tile whose pool is dry and whose last path has ended is tone-mapped and stored.
 #include <hip/hip_runtime.h>

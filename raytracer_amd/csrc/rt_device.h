@@ -116,14 +116,15 @@ __device__ __forceinline__ V3 random_unit(float u0, float u1) {
 // The terms are of the size of |C|^2 and cancel, so this form is only trusted up to a
 // margin: q is stored enlarged by FILTER_MARGIN*(|C|^2 + r^2), the per-ray threshold is
 // lowered by FILTER_MARGIN*|O|^2 (about four times the worst rounding error of the
-// chain), and every sphere that passes is decided by resolve_hit(), which forms the
-// discriminant from O - C, where rounding errors enter linearly in the coordinates.
+// chain), and every sphere that passes is decided by sphere_root(), which forms the
+// discriminant from O - C, where rounding errors enter linearly in the coordinates
+// (on the spot in the LDS-staged scan, from the candidate queue in the scalar-load scan).
 //
 // Spheres are stored in PAIRS so that one packed-FP32 instruction (v_pk_mul_f32 /
 // v_pk_fma_f32) serves two spheres:
 //   word 2j   = (x0, x1, y0, y1)      word 2j+1 = (z0, z1, q0, q1)
-// and their squared radii, which only resolve_hit() reads, in a separate array of one
-// float4 per group of four spheres.
+// and their squared radii, which only the LDS-staged scan's decision reads, in a separate
+// array of one float4 per group of four spheres.
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr float FILTER_MARGIN = 1.9073486328125e-6f; // 2^-19
@@ -182,7 +183,7 @@ __device__ __forceinline__ void stat_lanes(int k) {
 #define RT_STAT_LANES(k)
 #endif
 
-// The decision for one sphere that passed the filter (the rare path): the roots of
+// The decision for one sphere that passed the filter: the roots of
 // SphereObject::hitDetail (inc/RTObjects.h:135-149) with Interval::surrounds' open
 // interval (inc/RTGeometry.h:79-81), nearer root first.
 // With oc = O - C: hb = oc.dh, the discriminant is r^2 - |oc - hb dh|^2 (accumulated
@@ -233,7 +234,7 @@ struct QuadF {
 };
 #define RT_QUAD_STEP(Q, OP0, OP1) Q.F0 = OP0; Q.F1 = OP1
 
-// The rare path of a group: decide every sphere that passed the filter.
+// LDS-staged scan: decide, on the spot, every sphere of a group that passed the filter.
 __device__ __forceinline__ void resolve_quad(const RayK &r, V3 o, V3 dh, float4 A0, float4 B0, float4 A1, float4 B1,
                                              float4 R, const QuadF &q, float tmin, int idx, int self_id, float &best_t,
                                              int &best_id) {
