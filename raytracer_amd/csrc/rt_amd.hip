@@ -201,7 +201,8 @@ __device__ __forceinline__ void scan_scalar(const float4 *__restrict__ g, int nq
 }
 
 // Camera::genRay, src/Camera.cpp:124-135: jittered point on the 1x1 viewport.
-__device__ __forceinline__ void gen_ray(const KParams &p, int px, int py, float u0, float u1, V3 &o, V3 &d) {
+template <class P>
+__device__ __forceinline__ void gen_ray(const P &p, int px, int py, float u0, float u1, V3 &o, V3 &d) {
     V3 c = mk(p.cam[0], p.cam[1], p.cam[2]);
     V3 ul = mk(p.cam[3], p.cam[4], p.cam[5]);
     V3 right = mk(p.cam[6], p.cam[7], p.cam[8]);
@@ -257,7 +258,8 @@ struct Tile {
     int row0;     // output row of y0
 };
 
-__device__ __forceinline__ Tile decode_item(const KParams &p, unsigned item) {
+template <class P>
+__device__ __forceinline__ Tile decode_item(const P &p, unsigned item) {
     Tile t;
     int strip_local = (int)(item / (unsigned)p.tiles_per_strip);
     int rem = (int)(item - (unsigned)strip_local * (unsigned)p.tiles_per_strip);
@@ -282,17 +284,30 @@ __device__ __forceinline__ Tile decode_item(const KParams &p, unsigned item) {
 // short.  Inside a tile the wave runs the path loop described at the top of this file.
 template <int SRC, bool FULL>
 // the sphere-only variants are held to the register budget of five waves per SIMD
-__global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParams p, DeviceScene sc, uchar4 *__restrict__ rgba,
+__global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParams p_arg, DeviceScene sc_arg, uchar4 *__restrict__ rgba,
                                                             float4 *__restrict__ accum,
                                                             unsigned long long *__restrict__ rays_out,
                                                             unsigned *__restrict__ queue) {
+    // The scan needs 64 SGPRs for sphere words, so whatever else lives in SGPRs across it is spilled
+    // into VGPR lanes and comes back through v_readlane, which costs VALU issue slots, the kernel's
+    // bottleneck.  The launch parameters are therefore read from the kernel-argument segment (constant
+    // memory: scalar loads) and re-read after every scan instead of being kept.
+    struct KArgs {
+        KParams p;
+        DeviceScene sc;
+    };
+    cptr<KArgs> kargs = (cptr<KArgs>)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)p_arg;
+    (void)sc_arg;
+#define KP (kargs->p)
+#define KS (kargs->sc)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // per-wave state first (two accumulator slots of 3 channels x 64 pixels and their tile
     // descriptors), then the sphere words
     unsigned long long *acc_all = reinterpret_cast<unsigned long long *>(smem);
     float4 *lds_sph = reinterpret_cast<float4 *>(smem + WAVE_STATE_BYTES);
     // the squared radii follow the pair words of the resident list / of one streamed tile
-    float4 *lds_r2 = lds_sph + 4 * (SRC == SRC_LDS_STREAMED ? STREAM_QUADS : p.n_quads);
+    float4 *lds_r2 = lds_sph + 4 * (SRC == SRC_LDS_STREAMED ? STREAM_QUADS : KP.n_quads);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -302,10 +317,10 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
     cq.slot = reinterpret_cast<unsigned long long *>(smem + ACC_BYTES) + wave * 64;
     cq.ent = reinterpret_cast<unsigned *>(smem + ACC_BYTES + WAVES_PER_WG * 64 * sizeof(unsigned long long)) + wave * CAND_CAP;
 
-    const int nquads = p.n_quads; // groups of four spheres, padding included
+    const int nquads = KP.n_quads; // groups of four spheres, padding included
     if (SRC == SRC_LDS_RESIDENT) {
-        for (int i = threadIdx.x; i < 4 * nquads; i += WG_THREADS) lds_sph[i] = sc.pairs[i];
-        for (int i = threadIdx.x; i < nquads; i += WG_THREADS) lds_r2[i] = sc.r2q[i];
+        for (int i = threadIdx.x; i < 4 * nquads; i += WG_THREADS) lds_sph[i] = KS.pairs[i];
+        for (int i = threadIdx.x; i < nquads; i += WG_THREADS) lds_r2[i] = KS.r2q[i];
     }
     __syncthreads();
 
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
     ls.hself = -1;
     ls.nxt_self = -1;
     ls.nxt_valid = false;
-    const V3 cam_center = mk(p.cam[0], p.cam[1], p.cam[2]);
+    const V3 cam_center = mk(KP.cam[0], KP.cam[1], KP.cam[2]);
 
     // wave-uniform state: two tile slots.  At most one of them hands out samples (its pool is
     // open); the other may still have paths in flight from before its pool ran dry.
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
     int nvalid = 0;
     int cur_q = 0, cur_smp = 0;           // next (pixel, sample) of the open pool, pixels fastest
     float inv_nvalid = 0.f, inv_vw = 0.f; // reciprocals for the small index divisions below
-    const int tile_px = 1 << (p.tile_w_log2 + p.tile_h_log2);
+    const int tile_px = 1 << (KP.tile_w_log2 + KP.tile_h_log2);
 
     for (;;) {
         const bool wave_live = have0 || have1 || !queue_empty;
@@ -390,8 +405,8 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
             for (int base = 0; base < nquads; base += STREAM_QUADS) {
                 int cnt = min(STREAM_QUADS, nquads - base);
                 __syncthreads();
-                for (int i = threadIdx.x; i < 4 * cnt; i += WG_THREADS) lds_sph[i] = sc.pairs[4 * base + i];
-                for (int i = threadIdx.x; i < cnt; i += WG_THREADS) lds_r2[i] = sc.r2q[base + i];
+                for (int i = threadIdx.x; i < 4 * cnt; i += WG_THREADS) lds_sph[i] = KS.pairs[4 * base + i];
+                for (int i = threadIdx.x; i < cnt; i += WG_THREADS) lds_r2[i] = KS.r2q[base + i];
                 __syncthreads();
                 if (active)
                     scan_lds(lds_sph, lds_r2, cnt, 4 * base, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
@@ -401,10 +416,11 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         } else {
             // the whole wave scans: a lane without a ray passes no filter
             rk.thr = active ? rk.thr : __builtin_inff();
-            scan_scalar(sc.pairs, nquads, rk, pt.o, pt.dh, tmin, pt.self_id, lane, cq, sc.sph, p.n_spheres, best_t, best_id);
+            scan_scalar(KS.pairs, nquads, rk, pt.o, pt.dh, tmin, pt.self_id, lane, cq, KS.sph, KP.n_spheres, best_t, best_id);
         }
 
         // ---- shade (Camera::getRayColor, src/Camera.cpp:137-157) ----
+        asm volatile("" : "+s"(kargs)); // launch parameters are fetched again from here on, not held across the scan
         RT_SEC(1);
         bool bounce = false;
         Hit h;
@@ -417,23 +433,31 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         const bool shadow_ray = FULL && ls.light_i >= 0;
         if (active) {
             my_rays++;
-            if (pt.self_id >= 0) self_hit(pt.o, pt.dh, tmin, sc.sph[pt.self_id], pt.self_id, best_t, best_id);
+            if (pt.self_id >= 0) self_hit(pt.o, pt.dh, tmin, KS.sph[pt.self_id], pt.self_id, best_t, best_id);
             // the winner of the scan; FULL: merged with the other primitive kinds and the selection halo
             bool any_hit = best_id >= 0;
             int hit_obj = best_id; // HitRecord::object code
             int hit_self = best_id;
             bool halo = false;
             Closest c;
+            FullScene full; // a member-wise copy: class types cannot be copied out of the constant address space
             if (FULL) {
+                full.prims = KS.full.prims;
+                full.verts = KS.full.verts;
+                full.others = KS.full.others;
+                full.halo = KS.full.halo;
+                full.sph_gid = KS.full.sph_gid;
+                full.n_others = KS.full.n_others;
+                full.n_halo = KS.full.n_halo;
                 c.t = any_hit ? best_t * pt.inv_len : __builtin_inff();
-                c.prim = any_hit ? sc.full.sph_gid[best_id] : -1;
+                c.prim = any_hit ? full.sph_gid[best_id] : -1;
                 c.scale = 1.0f;
                 c.box_face = 0;
                 c.expanded = false;
-                for (int k = 0; k < sc.full.n_others; ++k) other_hit(sc.full, sc.full.others[k], pt.o, pt.d, TMIN, c);
+                for (int k = 0; k < full.n_others; ++k) other_hit(full, full.others[k], pt.o, pt.d, TMIN, c);
                 // the halo pass runs for primary rays only (hitExpandedState, src/Camera.cpp:141)
-                if (!shadow_ray && sc.full.n_halo > 0 && pt.depth == p.max_depth) {
-                    Closest e = halo_pass(sc.full, pt.o, pt.d, TMIN);
+                if (!shadow_ray && full.n_halo > 0 && pt.depth == KP.max_depth) {
+                    Closest e = halo_pass(full, pt.o, pt.d, TMIN);
                     if (e.expanded && e.t < c.t) c = e; // a plain halo-pass hit is the normal pass's own hit
                 }
                 any_hit = c.prim >= 0;
@@ -445,15 +469,15 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                     finished = true;
                 } else {
                     if (FULL) {
-                        h = finish_any(sc.full, pt.o, pt.d, c, hit_obj);
-                        const DPrim pr = load_prim(sc.full.prims, c.prim);
+                        h = finish_any(full, pt.o, pt.d, c, hit_obj);
+                        const DPrim pr = load_prim(full.prims, c.prim);
                         hit_mat = (int)pr.mat;
                         hit_self = (pr.type == PRIM_SPHERE && c.scale == 1.0f) ? pr.sph_local : -1;
                         halo = c.expanded;
                     } else {
-                        h = finish_hit(pt.o, pt.d, best_t * pt.inv_len, sc.sph[best_id]);
+                        h = finish_hit(pt.o, pt.d, best_t * pt.inv_len, KS.sph[best_id]);
                     }
-                    const DMat &m = FULL ? sc.mats[hit_mat] : sc.sph_mats[best_id];
+                    const DMat &m = FULL ? KS.mats[hit_mat] : KS.sph_mats[best_id];
                     at = m.albedo_type;
                     ef = m.emission_fuzz;
                     ior = m.ior_diffuse.x;
@@ -465,7 +489,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                     else bounce = true;
                     // diffuse and metal bounces start exactly on the sphere; the dielectric nudges its origin
                     next_self = __float_as_uint(at.w) <= 1u ? hit_self : -1;
-                    if (FULL && p.n_lights > 0) {
+                    if (FULL && KP.n_lights > 0) {
                         // Camera::computeDirectLighting (src/Camera.cpp:161-178): the hit is kept, the shadow
                         // queries run in the following iterations, then the path resumes or ends
                         ls.hp = h.p;
@@ -483,15 +507,15 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                 // not count, and cubes / polygons all carry the same null object (src/Camera.cpp:169-172)
                 int obj = OBJ_NONE;
                 if (any_hit) {
-                    const uint32_t ty = sc.full.prims[c.prim].type;
+                    const uint32_t ty = full.prims[c.prim].type;
                     obj = (ty == PRIM_CUBE || ty == PRIM_POLYGON) ? OBJ_NULL : c.prim;
                 }
                 const bool hitted = any_hit && obj != ls.hobj;
-                float4 idf = sc.mats[ls.hmat].ior_diffuse;
-                pt.L = pt.L + pt.T * light_direct(sc.lights[ls.light_i], cam_center, ls.hp, ls.hn,
+                float4 idf = KS.mats[ls.hmat].ior_diffuse;
+                pt.L = pt.L + pt.T * light_direct(KS.lights[ls.light_i], cam_center, ls.hp, ls.hn,
                                                   mk(idf.y, idf.z, idf.w), hitted);
                 ls.light_i++;
-                if (ls.light_i >= p.n_lights) {
+                if (ls.light_i >= KP.n_lights) {
                     ls.light_i = -1;
                     if (ls.nxt_valid) {
                         pt.T = pt.T * ls.att;
@@ -527,13 +551,13 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
             const int *d = desc + 8 * s;
             const int x0 = d[0], vw = d[2], vh = d[3], row0 = d[4];
             for (int q = lane; q < tile_px; q += 64) {
-                int lx = q & ((1 << p.tile_w_log2) - 1), ly = q >> p.tile_w_log2;
+                int lx = q & ((1 << KP.tile_w_log2) - 1), ly = q >> KP.tile_w_log2;
                 if (lx < vw && ly < vh) {
-                    size_t o = (size_t)(row0 + ly) * (size_t)p.width + (size_t)(x0 + lx);
+                    size_t o = (size_t)(row0 + ly) * (size_t)KP.width + (size_t)(x0 + lx);
                     float r = from_fixed(a[q]), g = from_fixed(a[MAX_TILE_PX + q]), b = from_fixed(a[2 * MAX_TILE_PX + q]);
-                    float cnt = (float)p.spp;
+                    float cnt = (float)KP.spp;
                     if (accum) {
-                        if (p.flags & RT_FLAG_ACCUMULATE) {
+                        if (KP.flags & RT_FLAG_ACCUMULATE) {
                             float4 prev = accum[o];
                             r += prev.x; g += prev.y; b += prev.z; cnt += prev.w;
                         }
@@ -567,11 +591,11 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                 unsigned it = 0;
                 if (lane == 0) it = atomicAdd(queue, 1u);
                 it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
-                if (it >= (unsigned)p.n_items) {
+                if (it >= (unsigned)KP.n_items) {
                     queue_empty = true;
                     break;
                 }
-                tile = decode_item(p, it);
+                tile = decode_item(KP, it);
                 nvalid = (tile.vw > 0 && tile.vh > 0) ? tile.vw * tile.vh : 0;
                 if (nvalid == 0) continue; // a tile outside the image: nothing to render or store
                 fill = have0 ? 1 : 0;
@@ -604,18 +628,18 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                 int wraps = (int)(((float)idx + 0.5f) * inv_nvalid);
                 int q = idx - wraps * nvalid;
                 int smp = cur_smp + wraps;
-                if (smp < p.spp) {
+                if (smp < KP.spp) {
                     int ly = (int)(((float)q + 0.5f) * inv_vw);
                     int lx = q - ly * tile.vw;
-                    pt.pix = fill * SLOT_WORDS + (ly << p.tile_w_log2) + lx;
+                    pt.pix = fill * SLOT_WORDS + (ly << KP.tile_w_log2) + lx;
                     px = tile.x0 + lx;
                     py = tile.y0 + ly;
-                    pt.gpix = rng_key((uint32_t)(py * p.width + px));
-                    pt.sample = rng_key((uint32_t)(smp + p.sample_offset));
+                    pt.gpix = rng_key((uint32_t)(py * KP.width + px));
+                    pt.sample = rng_key((uint32_t)(smp + KP.sample_offset));
                     pt.call = rng_key(0u);
                     pt.T = mk(1, 1, 1);
                     pt.L = mk(0, 0, 0);
-                    pt.depth = p.max_depth;
+                    pt.depth = KP.max_depth;
                     pt.self_id = -1;
                     fresh = true;
                 }
@@ -625,7 +649,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                 int wraps = (int)(((float)idx + 0.5f) * inv_nvalid);
                 cur_q = idx - wraps * nvalid;
                 cur_smp += wraps;
-                if (cur_smp >= p.spp) pool_open = false;
+                if (cur_smp >= KP.spp) pool_open = false;
             }
         }
 
@@ -634,11 +658,11 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         RT_SEC(5); // random words, primary ray or scatter
         if (fresh || bounce) {
             uint32_t w0, w1, w2, w3;
-            rng4_keyed(pt.gpix, pt.sample, pt.call, rng_key(p.seed), w0, w1, w2, w3);
+            rng4_keyed(pt.gpix, pt.sample, pt.call, rng_key(KP.seed), w0, w1, w2, w3);
             pt.call += RNG_MUL;
             V3 nd;
             if (fresh) {
-                gen_ray(p, px, py, u01(w0), u01(w1), pt.o, nd);
+                gen_ray(KP, px, py, u01(w0), u01(w1), pt.o, nd);
                 if (FULL) ls.light_i = -1;
                 set_dir(pt, nd);
             } else {
@@ -646,7 +670,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
                 scatter(__float_as_uint(at.w), mk(at.x, at.y, at.z), ef.w, ior, pt.d, h, u01(w0), u01(w1), u01(w2), att,
                         no, nd);
                 const int nself = next_self;
-                if (FULL && p.n_lights > 0) {
+                if (FULL && KP.n_lights > 0) {
                     ls.nxt_o = no;
                     ls.nxt_d = nd;
                     ls.att = att;
@@ -662,7 +686,7 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         if (FULL && ls.light_i >= 0 && pt.pix >= 0) {
             // (next) shadow ray: from the hit point towards the light, direction unnormalised as in
             // the reference (src/Camera.cpp:166)
-            float4 lp = sc.lights[ls.light_i].pos_pow;
+            float4 lp = KS.lights[ls.light_i].pos_pow;
             pt.o = ls.hp;
             set_dir(pt, mk(lp.x, lp.y, lp.z) - ls.hp);
             pt.self_id = ls.hself;
@@ -691,6 +715,8 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
         for (int off = 32; off > 0; off >>= 1) my_rays += __shfl_down(my_rays, off, 64);
         if (lane == 0 && my_rays) atomicAdd(rays_out, my_rays);
     }
+#undef KP
+#undef KS
 }
 
 // ---------------------------------------------------------------------------
