@@ -284,10 +284,10 @@ __device__ __forceinline__ Tile decode_item(const P &p, unsigned item) {
 // short.  Inside a tile the wave runs the path loop described at the top of this file.
 template <int SRC, bool FULL>
 // the sphere-only variants are held to the register budget of five waves per SIMD
-__global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParams p_arg, DeviceScene sc_arg, uchar4 *__restrict__ rgba,
-                                                            float4 *__restrict__ accum,
-                                                            unsigned long long *__restrict__ rays_out,
-                                                            unsigned *__restrict__ queue) {
+__global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParams p_arg, DeviceScene sc_arg, uchar4 *__restrict__ rgba_arg,
+                                                            float4 *__restrict__ accum_arg,
+                                                            unsigned long long *__restrict__ rays_out_arg,
+                                                            unsigned *__restrict__ queue_arg) {
     // The scan needs 64 SGPRs for sphere words, so whatever else lives in SGPRs across it is spilled
     // into VGPR lanes and comes back through v_readlane, which costs VALU issue slots, the kernel's
     // bottleneck.  The launch parameters are therefore read from the kernel-argument segment (constant
@@ -295,12 +295,24 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
     struct KArgs {
         KParams p;
         DeviceScene sc;
+        uchar4 *rgba;
+        float4 *accum;
+        unsigned long long *rays_out;
+        unsigned *queue;
     };
     cptr<KArgs> kargs = (cptr<KArgs>)__builtin_amdgcn_kernarg_segment_ptr();
     (void)p_arg;
     (void)sc_arg;
+    (void)rgba_arg;
+    (void)accum_arg;
+    (void)rays_out_arg;
+    (void)queue_arg;
 #define KP (kargs->p)
 #define KS (kargs->sc)
+#define rgba (kargs->rgba)
+#define accum (kargs->accum)
+#define rays_out (kargs->rays_out)
+#define queue (kargs->queue)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // per-wave state first (two accumulator slots of 3 channels x 64 pixels and their tile
     // descriptors), then the sphere words
@@ -717,6 +729,10 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParam
     }
 #undef KP
 #undef KS
+#undef rgba
+#undef accum
+#undef rays_out
+#undef queue
 }
 
 // ---------------------------------------------------------------------------
