@@ -111,6 +111,16 @@ struct DeviceScene {
     FullScene full; // general primitive list (used by the FULL kernel variants only)
 };
 
+// Everything a render launch is given, as the kernel's one argument.
+struct KArgs {
+    KParams p;
+    DeviceScene sc;
+    uchar4 *rgba;
+    float4 *accum;                // may be null
+    unsigned long long *rays_out; // may be null
+    unsigned *queue;              // work counter, zero at launch
+};
+
 // Where the scan loop takes the sphere words from.
 enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2 };
 
@@ -284,29 +294,14 @@ __device__ __forceinline__ Tile decode_item(const P &p, unsigned item) {
 // short.  Inside a tile the wave runs the path loop described at the top of this file.
 template <int SRC, bool FULL>
 // the sphere-only variants are held to the register budget of five waves per SIMD
-__global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KParams p_arg, DeviceScene sc_arg, uchar4 *__restrict__ rgba_arg,
-                                                            float4 *__restrict__ accum_arg,
-                                                            unsigned long long *__restrict__ rays_out_arg,
-                                                            unsigned *__restrict__ queue_arg) {
+__global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KArgs args) {
     // The scan needs 64 SGPRs for sphere words, so whatever else lives in SGPRs across it is spilled
     // into VGPR lanes and comes back through v_readlane, which costs VALU issue slots, the kernel's
     // bottleneck.  The launch parameters are therefore read from the kernel-argument segment (constant
-    // memory: scalar loads) and re-read after every scan instead of being kept.
-    struct KArgs {
-        KParams p;
-        DeviceScene sc;
-        uchar4 *rgba;
-        float4 *accum;
-        unsigned long long *rays_out;
-        unsigned *queue;
-    };
+    // memory, scalar loads; the single argument sits at its start) and re-read after every scan
+    // instead of being kept.
     cptr<KArgs> kargs = (cptr<KArgs>)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)p_arg;
-    (void)sc_arg;
-    (void)rgba_arg;
-    (void)accum_arg;
-    (void)rays_out_arg;
-    (void)queue_arg;
+    (void)args;
 #define KP (kargs->p)
 #define KS (kargs->sc)
 #define rgba (kargs->rgba)
@@ -1647,8 +1642,8 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
         src = resident ? SRC_LDS_RESIDENT : SRC_LDS_STREAMED;
         lds += (size_t)(resident ? (ctx->n_quads > 0 ? ctx->n_quads : 1) : STREAM_QUADS) * 5 * sizeof(float4);
     }
-#define RT_LAUNCH(S, L)                                                                                   \
-    hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, k, sc, o_rgba, o_acc, o_rays, queue)
+    const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, queue};
+#define RT_LAUNCH(S, L) hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, ka)
     if (src == SRC_SCALAR) { if (full) RT_LAUNCH(SRC_SCALAR, true); else RT_LAUNCH(SRC_SCALAR, false); }
     else if (src == SRC_LDS_RESIDENT) { if (full) RT_LAUNCH(SRC_LDS_RESIDENT, true); else RT_LAUNCH(SRC_LDS_RESIDENT, false); }
     else { if (full) RT_LAUNCH(SRC_LDS_STREAMED, true); else RT_LAUNCH(SRC_LDS_STREAMED, false); }
