@@ -70,6 +70,7 @@ __device__ __forceinline__ void to_fixed3(V3 L, unsigned long long &fx, unsigned
     fy = to_fixed_magnitude(L.y);
     fz = to_fixed_magnitude(L.z);
     if (__ballot(fminf(fminf(L.x, L.y), L.z) < 0.0f)) {
+        asm volatile(""); // keeps this a branch: folded into selects it would run for every sample
         fx = L.x < 0.0f ? 0ull - fx : fx;
         fy = L.y < 0.0f ? 0ull - fy : fy;
         fz = L.z < 0.0f ? 0ull - fz : fz;
