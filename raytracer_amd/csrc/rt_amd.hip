@@ -29,6 +29,7 @@
 #include "../../include/rt_amd.h"
 #include "rt_device.h"
 #include "rt_prims.h"
+#include "rt_mfma.h"
 
 using namespace rt;
 
@@ -49,6 +50,21 @@ constexpr size_t ACC_BYTES = WAVES_PER_WG * WAVE_LDS_WORDS * sizeof(unsigned lon
 // per-wave candidate queue and closest-hit slots of the deferred sphere decisions (rt_device.h)
 constexpr size_t CQ_BYTES = WAVES_PER_WG * (CAND_CAP * sizeof(unsigned) + 64 * sizeof(unsigned long long));
 constexpr size_t WAVE_STATE_BYTES = ACC_BYTES + CQ_BYTES;
+
+// Where the scan loop takes the sphere words from.
+enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2, SRC_MFMA = 3 };
+
+// The matrix-core variant shares one filter table per workgroup, so its workgroups are as large as
+// they come (16 waves: one workgroup per CU at four waves per SIMD), and its queue only ever holds
+// the remainder of one batch plus one turn of the recording loop.
+constexpr size_t MF_LDS_BYTES = 160 * 1024; // LDS of one CU: what a workgroup of the matrix-core variant may use
+constexpr int wg_threads_of(int src) { return src == SRC_MFMA ? 1024 : WG_THREADS; }
+constexpr int cand_cap_of(int src) { return src == SRC_MFMA ? 128 : CAND_CAP; }
+constexpr size_t acc_bytes_of(int src) { return (size_t)(wg_threads_of(src) / 64) * WAVE_LDS_WORDS * sizeof(unsigned long long); }
+constexpr size_t wave_state_bytes_of(int src) {
+    return acc_bytes_of(src) + (size_t)(wg_threads_of(src) / 64) * (cand_cap_of(src) * sizeof(unsigned) + 64 * sizeof(unsigned long long));
+}
+static_assert(wave_state_bytes_of(SRC_SCALAR) == WAVE_STATE_BYTES, "the plain variants keep their layout");
 
 // Radiance sums are kept in signed 40.24 fixed point: integer addition is exact, so a pixel's sum
 // does not depend on the order in which its samples finish -- which changes with the tile that
@@ -96,6 +112,7 @@ struct KParams {
     int n_quads;     // sphere quads to scan (padding included)
     int n_spheres;   // spheres of the scene
     int n_lights;    // lights shaded at every hit (0 unless RT_FLAG_DIRECT_LIGHT)
+    MfmaFrame mf;    // frame of the matrix-core filter table (SRC_MFMA)
     float inv_w, inv_h;
     float cam[12];   // center, upper_left, right, down
 };
@@ -109,6 +126,7 @@ struct DeviceScene {
     const DMat *sph_mats; // the material of every sphere, by sphere index: one load instead of two dependent ones
     const DMat *mats;
     const DLight *lights;
+    const uint4v *mf_table; // matrix-core filter table, MF_BLOCK_WORDS 16-byte words per 32 spheres
     FullScene full; // general primitive list (used by the FULL kernel variants only)
 };
 
@@ -121,9 +139,6 @@ struct KArgs {
     unsigned long long *rays_out; // may be null
     unsigned *queue;              // work counter, zero at launch
 };
-
-// Where the scan loop takes the sphere words from.
-enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2 };
 
 // Scan `nquads` groups of four spheres held in LDS (every lane reads the same address:
 // a broadcast read) for one ray.
@@ -295,7 +310,8 @@ __device__ __forceinline__ Tile decode_item(const P &p, unsigned item) {
 // short.  Inside a tile the wave runs the path loop described at the top of this file.
 template <int SRC, bool FULL>
 // the sphere-only variants are held to the register budget of five waves per SIMD
-__global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KArgs args) {
+__global__ __launch_bounds__(wg_threads_of(SRC), SRC == SRC_MFMA ? 4 : (FULL ? 1 : 5)) void render_kernel(KArgs args) {
+    constexpr int WGT = wg_threads_of(SRC), NW = WGT / 64;
     // The scan needs 64 SGPRs for sphere words, so whatever else lives in SGPRs across it is spilled
     // into VGPR lanes and comes back through v_readlane, which costs VALU issue slots, the kernel's
     // bottleneck.  The launch parameters are therefore read from the kernel-argument segment (constant
@@ -313,7 +329,8 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KArgs 
     // per-wave state first (two accumulator slots of 3 channels x 64 pixels and their tile
     // descriptors), then the sphere words
     unsigned long long *acc_all = reinterpret_cast<unsigned long long *>(smem);
-    float4 *lds_sph = reinterpret_cast<float4 *>(smem + WAVE_STATE_BYTES);
+    float4 *lds_sph = reinterpret_cast<float4 *>(smem + wave_state_bytes_of(SRC));
+    const uint4v *lds_tab = reinterpret_cast<const uint4v *>(smem + wave_state_bytes_of(SRC)); // SRC_MFMA
     // the squared radii follow the pair words of the resident list / of one streamed tile
     float4 *lds_r2 = lds_sph + 4 * (SRC == SRC_LDS_STREAMED ? STREAM_QUADS : KP.n_quads);
 
@@ -322,13 +339,17 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KArgs 
     unsigned long long *acc = acc_all + wave * WAVE_LDS_WORDS;
     int *desc = reinterpret_cast<int *>(acc + 2 * SLOT_WORDS); // slot s: desc[8 s ...] = x0, y0, vw, vh, row0
     CandQ cq;
-    cq.slot = reinterpret_cast<unsigned long long *>(smem + ACC_BYTES) + wave * 64;
-    cq.ent = reinterpret_cast<unsigned *>(smem + ACC_BYTES + WAVES_PER_WG * 64 * sizeof(unsigned long long)) + wave * CAND_CAP;
+    cq.slot = reinterpret_cast<unsigned long long *>(smem + acc_bytes_of(SRC)) + wave * 64;
+    cq.ent = reinterpret_cast<unsigned *>(smem + acc_bytes_of(SRC) + NW * 64 * sizeof(unsigned long long)) + wave * cand_cap_of(SRC);
 
     const int nquads = KP.n_quads; // groups of four spheres, padding included
     if (SRC == SRC_LDS_RESIDENT) {
-        for (int i = threadIdx.x; i < 4 * nquads; i += WG_THREADS) lds_sph[i] = KS.pairs[i];
-        for (int i = threadIdx.x; i < nquads; i += WG_THREADS) lds_r2[i] = KS.r2q[i];
+        for (int i = threadIdx.x; i < 4 * nquads; i += WGT) lds_sph[i] = KS.pairs[i];
+        for (int i = threadIdx.x; i < nquads; i += WGT) lds_r2[i] = KS.r2q[i];
+    }
+    if (SRC == SRC_MFMA) {
+        uint4v *dst = reinterpret_cast<uint4v *>(smem + wave_state_bytes_of(SRC));
+        for (int i = threadIdx.x; i < KP.mf.n_blocks * MF_BLOCK_WORDS; i += WGT) dst[i] = KS.mf_table[i];
     }
     __syncthreads();
 
@@ -413,14 +434,16 @@ __global__ __launch_bounds__(WG_THREADS, FULL ? 1 : 5) void render_kernel(KArgs 
             for (int base = 0; base < nquads; base += STREAM_QUADS) {
                 int cnt = min(STREAM_QUADS, nquads - base);
                 __syncthreads();
-                for (int i = threadIdx.x; i < 4 * cnt; i += WG_THREADS) lds_sph[i] = KS.pairs[4 * base + i];
-                for (int i = threadIdx.x; i < cnt; i += WG_THREADS) lds_r2[i] = KS.r2q[base + i];
+                for (int i = threadIdx.x; i < 4 * cnt; i += WGT) lds_sph[i] = KS.pairs[4 * base + i];
+                for (int i = threadIdx.x; i < cnt; i += WGT) lds_r2[i] = KS.r2q[base + i];
                 __syncthreads();
                 if (active)
                     scan_lds(lds_sph, lds_r2, cnt, 4 * base, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
             }
         } else if (SRC == SRC_LDS_RESIDENT) {
             if (active) scan_lds(lds_sph, lds_r2, nquads, 0, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
+        } else if (SRC == SRC_MFMA) {
+            scan_mfma(lds_tab, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph, best_t, best_id);
         } else {
             // the whole wave scans: a lane without a ray passes no filter
             rk.thr = active ? rk.thr : __builtin_inff();
@@ -1156,6 +1179,12 @@ struct rt_ctx {
     float4 *d_r2q = nullptr;
     int n_quads = 0;
     bool scalar_source = true;
+    // matrix-core filter table (rt_mfma.h): built with every scene it can serve
+    uint4v *d_mf_table = nullptr;
+    MfmaFrame mf{};
+    bool mf_usable = false;  // the scene has a table and it fits in LDS
+    bool mf_wanted = true;   // RT_AMD_SPHERE_SOURCE did not ask for another source
+    int mf_wgs_per_cu = 1;   // resident workgroups of the matrix-core kernel per CU (set at the first launch)
     unsigned char *d_queue = nullptr; // ring of work-item counters of the persistent render kernel
     unsigned queue_next = 0;          // next slot of the ring
     unsigned char *d_scratch = nullptr; // this device's copy of `scratch` (rt_render_noalloc)
@@ -1335,6 +1364,12 @@ RT_API int rt_create(int device, rt_ctx **out) {
             delete ctx;
             return RT_ERR_HIP;
         }
+    // the matrix-core variant wants the whole LDS of a CU; a device that will not give it runs the other variants
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_MFMA, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)MF_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->mf_wanted = false;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cus = prop.multiProcessorCount;
@@ -1352,6 +1387,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
     if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (v >= 0 && v <= 3) ctx->force_tile = v; }
     const char *src = getenv("RT_AMD_SPHERE_SOURCE");
     ctx->scalar_source = !(src && strcmp(src, "lds") == 0);
+    ctx->mf_wanted = ctx->mf_wanted && !(src && (strcmp(src, "lds") == 0 || strcmp(src, "scalar") == 0));
     *out = ctx;
     return RT_OK;
 }
@@ -1380,6 +1416,7 @@ DeviceScene device_scene(const rt_ctx *ctx) {
     sc.mats = ctx->d_mats;
     sc.sph_mats = ctx->d_sph_mats;
     sc.lights = ctx->d_lights;
+    sc.mf_table = ctx->d_mf_table;
     sc.full.prims = as_const(ctx->d_prims);
     sc.full.verts = as_const(ctx->d_verts);
     sc.full.others = as_const(ctx->d_others);
@@ -1395,6 +1432,135 @@ int to_device(rt_ctx *ctx, T **dst, const std::vector<T> &src) {
     HIP_TRY(ctx, reserve(ctx, (void **)dst, src.size() * sizeof(T)));
     if (!src.empty()) HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return RT_OK;
+}
+
+// float -> f16 bits, round to nearest even (values beyond the f16 range clamp to its largest)
+uint16_t half_rn(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int e = (int)((x >> 23) & 0xffu) - 127 + 15;
+    uint32_t m = x & 0x7fffffu;
+    if (e >= 31) return (uint16_t)(sign | 0x7bffu);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t hm = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1u))) hm++;
+        return (uint16_t)(sign | hm);
+    }
+    uint32_t h = sign | ((uint32_t)e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++; // a carry into the exponent is the right result
+    return (uint16_t)((h & 0x7fffu) >= 0x7c00u ? (sign | 0x7bffu) : h);
+}
+double half_value(uint16_t h) {
+    const int e = (h >> 10) & 0x1f, m = h & 0x3ff;
+    const double v = e == 0 ? std::ldexp((double)m, -24) : std::ldexp((double)(m | 0x400), e - 25);
+    return (h & 0x8000) ? -v : v;
+}
+
+// The per-sphere side of the matrix-core filter (rt_mfma.h): frame, big spheres, and the table in
+// the lane layout of the 32x32x16 A operand.  `ok` is false when the scene cannot use it.
+struct MfTable {
+    std::vector<uint32_t> words;
+    MfmaFrame fr;
+    bool ok = false;
+};
+
+MfTable build_mf_table(const std::vector<float4> &sph) {
+    MfTable T;
+    memset(&T.fr, 0, sizeof T.fr);
+    const int n = (int)sph.size();
+    if (n <= SMALL_SCENE) return T;
+    for (const float4 &s : sph)
+        if (!std::isfinite(s.x) || !std::isfinite(s.y) || !std::isfinite(s.z) || !std::isfinite(s.w)) return T;
+    std::vector<char> big((size_t)n, 0);
+    double c0[3] = {0, 0, 0}, Rs = 0;
+    // bounding-box centre of the spheres in the table, their reach from it, and the largest of them
+    auto bound = [&](double c[3], int &far_i) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            if (big[i]) continue;
+            const double cc[3] = {sph[i].x, sph[i].y, sph[i].z}, r = std::fabs((double)sph[i].w);
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(lo[k], cc[k] - r);
+                hi[k] = std::max(hi[k], cc[k] + r);
+            }
+            ++cnt;
+        }
+        far_i = -1;
+        if (cnt == 0) return 0.0;
+        for (int k = 0; k < 3; ++k) c[k] = 0.5 * (lo[k] + hi[k]);
+        double reach = 0, largest = -1;
+        for (int i = 0; i < n; ++i) {
+            if (big[i]) continue;
+            const double dx = sph[i].x - c[0], dy = sph[i].y - c[1], dz = sph[i].z - c[2], r = std::fabs((double)sph[i].w);
+            reach = std::max(reach, std::sqrt(dx * dx + dy * dy + dz * dz) + r);
+            if (r > largest) { largest = r; far_i = i; }
+        }
+        return reach;
+    };
+    int n_big = 0, far_i = -1;
+    Rs = bound(c0, far_i);
+    // the largest sphere is decided outside the table if the cloud is less than half as wide without it
+    while (n_big < MF_MAX_BIG && n - n_big > 1 && far_i >= 0) {
+        big[far_i] = 1;
+        double c1[3];
+        int far1 = -1;
+        const double R1 = bound(c1, far1);
+        if (!(R1 < 0.5 * Rs)) { big[far_i] = 0; break; }
+        T.fr.big[n_big++] = far_i;
+        memcpy(c0, c1, sizeof c0);
+        Rs = R1;
+        far_i = far1;
+    }
+    if (!(Rs > 1e-30) || !std::isfinite(Rs)) return T;
+    const float scale = MF_SCALE / (float)Rs;
+    if (!std::isfinite(scale) || !(scale > 0.0f)) return T;
+    // the kernel computes O' = (O - c0) * scale in float: the table follows those floats exactly
+    const float c0f[3] = {(float)c0[0], (float)c0[1], (float)c0[2]};
+    const double inv_rs = (double)scale / (double)MF_SCALE;
+    const int n_blocks = (n + MF_BLOCK - 1) / MF_BLOCK;
+    T.fr.cx = c0f[0]; T.fr.cy = c0f[1]; T.fr.cz = c0f[2];
+    T.fr.scale = scale;
+    T.fr.n_blocks = n_blocks;
+    T.fr.n_big = n_big;
+    T.words.assign((size_t)n_blocks * MF_BLOCK_WORDS * 4, 0u);
+    for (int row = 0; row < n_blocks * MF_BLOCK; ++row) {
+        uint16_t hi[9] = {0}, lo[9] = {0}, q_hi = half_rn(MF_NEVER), q_lo = 0;
+        const uint16_t unit = half_rn(-MF_SCALE);
+        if (row < n && !big[row]) {
+            const double x = ((double)sph[row].x - c0f[0]) * inv_rs, y = ((double)sph[row].y - c0f[1]) * inv_rs,
+                         z = ((double)sph[row].z - c0f[2]) * inv_rs, r = (double)sph[row].w * inv_rs;
+            const double feat[9] = {x * x, y * y, z * z, 2 * x * y, 2 * x * z, 2 * y * z, 2 * x, 2 * y, 2 * z};
+            for (int f = 0; f < 9; ++f) {
+                const double S = -(double)MF_SCALE * feat[f];
+                hi[f] = half_rn((float)S);
+                lo[f] = half_rn((float)(S - half_value(hi[f])));
+            }
+            const double Q = -(double)MF_SCALE * (r * r - (x * x + y * y + z * z));
+            q_hi = half_rn((float)Q);
+            q_lo = half_rn((float)(Q - half_value(q_hi)));
+        }
+        uint32_t w[16];
+        auto pack = [](uint16_t a, uint16_t b) { return (uint32_t)a | ((uint32_t)b << 16); };
+        for (int f = 0; f < 9; ++f) w[f] = pack(hi[f], hi[f]);
+        for (int g = 0; g < 4; ++g) w[9 + g] = pack(lo[2 * g], lo[2 * g + 1]);
+        w[13] = pack(lo[8], q_hi);
+        w[14] = pack(q_lo, 0);
+        w[15] = pack(unit, unit);
+        const int blk = row / MF_BLOCK, r = row % MF_BLOCK;
+        for (int step = 0; step < 2; ++step)
+            for (int h = 0; h < 2; ++h)
+                for (int i = 0; i < 4; ++i)
+                    T.words[(((size_t)blk * 2 + step) * 64 + (size_t)(32 * h + r)) * 4 + i] = w[8 * step + 4 * h + i];
+    }
+    T.ok = true;
+    return T;
 }
 
 // Builds every device array of a scene from the general primitive list.
@@ -1493,6 +1659,14 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
     if ((rc = to_device(ctx, &ctx->d_sph, sph)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_pairs, pairs)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_r2q, r2q)) != RT_OK) return rc;
+    MfTable mft = build_mf_table(sph);
+    ctx->mf_usable = false;
+    if (mft.ok && wave_state_bytes_of(SRC_MFMA) + mft.words.size() * 4 <= MF_LDS_BYTES) {
+        HIP_TRY(ctx, reserve(ctx, (void **)&ctx->d_mf_table, mft.words.size() * 4));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_mf_table, mft.words.data(), mft.words.size() * 4, hipMemcpyHostToDevice));
+        ctx->mf = mft.fr;
+        ctx->mf_usable = true;
+    }
     if ((rc = to_device(ctx, &ctx->d_mat_id, mid)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_mats, mats)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_sph_mats, sph_mats)) != RT_OK) return rc;
@@ -1643,9 +1817,28 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
         src = resident ? SRC_LDS_RESIDENT : SRC_LDS_STREAMED;
         lds += (size_t)(resident ? (ctx->n_quads > 0 ? ctx->n_quads : 1) : STREAM_QUADS) * 5 * sizeof(float4);
     }
+    if (ctx->mf_usable && ctx->mf_wanted && !full) {
+        // matrix-core filter: one table per workgroup in LDS, as many workgroups as stay resident
+        src = SRC_MFMA;
+        k.mf = ctx->mf;
+        lds = wave_state_bytes_of(SRC_MFMA) + (size_t)ctx->mf.n_blocks * MF_BLOCK_WORDS * 16;
+        int resident = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                         &resident, reinterpret_cast<const void *>(&render_kernel<SRC_MFMA, false>),
+                         wg_threads_of(SRC_MFMA), lds));
+        if (resident < 1) return fail(ctx, RT_ERR_HIP, "the matrix-core render kernel does not fit on a CU");
+        const int wpw = wg_threads_of(SRC_MFMA) / 64;
+        want = (items + wpw - 1) / wpw;
+        cap = (long long)ctx->n_cus * resident;
+        grid = dim3((unsigned)(want < cap ? want : cap));
+        block = dim3(wg_threads_of(SRC_MFMA));
+    } else {
+        memset(&k.mf, 0, sizeof k.mf);
+    }
     const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, queue};
 #define RT_LAUNCH(S, L) hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, ka)
-    if (src == SRC_SCALAR) { if (full) RT_LAUNCH(SRC_SCALAR, true); else RT_LAUNCH(SRC_SCALAR, false); }
+    if (src == SRC_MFMA) RT_LAUNCH(SRC_MFMA, false);
+    else if (src == SRC_SCALAR) { if (full) RT_LAUNCH(SRC_SCALAR, true); else RT_LAUNCH(SRC_SCALAR, false); }
     else if (src == SRC_LDS_RESIDENT) { if (full) RT_LAUNCH(SRC_LDS_RESIDENT, true); else RT_LAUNCH(SRC_LDS_RESIDENT, false); }
     else { if (full) RT_LAUNCH(SRC_LDS_STREAMED, true); else RT_LAUNCH(SRC_LDS_STREAMED, false); }
 #undef RT_LAUNCH

@@ -1,0 +1,204 @@
+// rt_mfma.h — the sphere filter of the scan on the matrix cores (gfx950 v_mfma_f32_32x32x16_f16).
+//
+// The filter of rt_device.h is a bilinear form in per-sphere and per-ray quantities.  In a frame
+// centred on the sphere cloud and scaled by its radius Rs (C' = (C - c0)/Rs, O' = (O - c0)/Rs, the
+// unit direction dh unchanged, p = O' - dh (O'.dh) the point of the ray's line nearest the centre):
+//
+//   disc/Rs^2 = sum_ij C'_i C'_j dh_i dh_j  +  2 C'.p  +  (r^2 - |C - c0|^2)/Rs^2  -  |p|^2
+//
+// which is the dot product of eleven per-sphere numbers (x^2, y^2, z^2, 2xy, 2xz, 2yz, 2x, 2y, 2z, q, 1)
+// with eleven per-ray numbers (dx^2, dy^2, dz^2, dx dy, dx dz, dy dz, px, py, pz, 1, m - |p|^2; m is the
+// margin below).  One 32x32x16 MFMA pair (K = 32) evaluates it for 32 spheres x 32 rays in 64 cycles of
+// the matrix pipe; the packed-FP32 chain needs 7 instructions of 4.4 cycles per sphere PAIR per 64 rays.
+//
+// f16 carries 11 significant bits, so every number is split into a high and a low half-float
+// (a = a_hi + a_lo, 22 bits) and each product a*b enters the sum as a_hi b_hi + a_hi b_lo + a_lo b_hi:
+// 9 x 3 slots for the geometric terms, 2 for q (its partner is the constant 1), 2 for the per-ray term
+// (partner 1) = 31 of the 32 k slots.  Both sides are scaled by 2^10 so that the low halves of all
+// but negligible numbers are normal f16 values.  What is dropped and rounded is bounded by about
+// 2^-19 of sum |a_i b_i| <= 5 (frame units); the accumulation in the matrix pipe adds less than that.
+// The per-ray term carries the margin m = MF_MARGIN + 2^-20 max|O'_i| (the second part covers the
+// rounding of O' itself for origins far from the cloud), so the sign of the result errs only towards
+// "candidate": like the packed filter, this one may pass a sphere the ray misses and never drops one it
+// hits.  Everything that passes is decided by sphere_root() from the candidate queue, so a frame has
+// the same bytes whichever filter ran.
+//
+// The per-sphere side is NEGATED on the host: the result is negative for a candidate, and the sign
+// bits of the 32 accumulator registers of a lane are gathered with one v_alignbit_b32 each.
+//
+// A sphere much larger than the cloud of the others (a ground sphere) would set Rs and with it the
+// resolution of the frame; up to MF_MAX_BIG such spheres are kept out of the table (their rows never
+// pass) and decided directly for every ray.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+
+constexpr int MF_BLOCK = 32;             // spheres per table block (rows of one MFMA tile)
+constexpr int MF_BLOCK_WORDS = 2 * 64;   // 16-byte words per block: two k-steps x 64 lanes
+constexpr int MF_MAX_BIG = 8;            // spheres decided outside the table
+constexpr float MF_SCALE = 1024.0f;      // both operand sides are scaled by this
+constexpr float MF_MARGIN = 3.0517578125e-5f;     // 2^-15, in frame units (radius of the cloud = 1)
+constexpr float MF_MARGIN_FAR = 9.5367431640625e-7f; // 2^-20 per frame unit of max|O'_i|
+constexpr float MF_CULL = 1.002f;        // a line farther than this from the centre meets no table sphere
+constexpr float MF_NEVER = 60000.0f;     // magnitude that outweighs every other term
+
+// What the kernel needs to know about the table (part of the launch parameters).
+struct MfmaFrame {
+    float cx, cy, cz; // c0: centre of the cloud
+    float scale;      // MF_SCALE / Rs
+    int n_blocks;     // table blocks of 32 spheres (row = sphere index; rows past the list never pass)
+    int n_big;
+    int big[MF_MAX_BIG]; // indices of the spheres decided directly
+};
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+
+__device__ __forceinline__ uint32_t pack_rtz(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+__device__ __forceinline__ float half_lo(uint32_t w) { return (float)__builtin_bit_cast(half2v, w).x; }
+__device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_bit_cast(half2v, w).y; }
+
+// The ray side of the product, as the B operand of both k-steps for the two 32-ray halves of the wave.
+struct RayOperand {
+    half8 b[2][2]; // [ray block: lanes 0-31 / 32-63][k-step]
+};
+
+// k slots, two per 32-bit word w (sphere side in brackets, both sides carry MF_SCALE):
+//   w = f, f < 9 : (a_hi[f], a_lo[f])          [S_hi[f], S_hi[f]]
+//   w = 9..12    : (a_hi[2g], a_hi[2g+1])      [S_lo[2g], S_lo[2g+1]]     g = w - 9
+//   w = 13       : (a_hi[8], 1)                [S_lo[8], Q_hi]
+//   w = 14       : (1, 0)                      [Q_lo, 0]
+//   w = 15       : (t_hi, t_lo)                [1, 1]
+// Lane l of a 32x32x16 operand holds k = 8 (l >> 5) + j of its row / column (j = 0..7), so a lane's own
+// sixteen words are exchanged between the wave's halves (v_permlane32_swap) into the four operands.
+__device__ __forceinline__ RayOperand mfma_ray_operand(V3 o, V3 dh, bool live, float cx, float cy, float cz, float scale) {
+    // O' scaled by MF_SCALE; p in two steps: the first lands on the line near the centre (any multiple
+    // of dh does), the second removes what is left along dh, so p's error does not grow with |O'|^2
+    const V3 oc = mk((o.x - cx) * scale, (o.y - cy) * scale, (o.z - cz) * scale);
+    const V3 o2 = madd(oc, dh, -dot(oc, dh));
+    const V3 p = madd(o2, dh, -dot(o2, dh));
+    const float pp = dot(p, p) * (1.0f / MF_SCALE); // MF_SCALE * |p|^2
+    const float far = fmaxf(fmaxf(fabsf(oc.x), fabsf(oc.y)), fabsf(oc.z)); // MF_SCALE * max|O'_i|
+    float t = fmaf(MF_MARGIN_FAR, far, MF_MARGIN * MF_SCALE) - pp;
+    live = live && pp <= MF_CULL * MF_CULL * MF_SCALE;
+    const V3 ds = dh * 32.0f; // sqrt(MF_SCALE)
+    float a[9] = {ds.x * ds.x, ds.y * ds.y, ds.z * ds.z, ds.x * ds.y, ds.x * ds.z, ds.y * ds.z, p.x, p.y, p.z};
+    if (!live) {
+#pragma unroll
+        for (int f = 0; f < 9; ++f) a[f] = 0.0f;
+        t = -MF_NEVER;
+    }
+    uint32_t w[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w[9 + g] = pack_rtz(a[2 * g], a[2 * g + 1]);
+    w[13] = pack_rtz(a[8], MF_SCALE);
+    w[14] = 0x00006400u; // (1024, 0)
+#pragma unroll
+    for (int f = 0; f < 9; ++f) {
+        const uint32_t hw = w[9 + (f >> 1)];
+        const float hi = (f & 1) ? half_hi(hw) : half_lo(hw);
+        w[f] = pack_rtz(hi, a[f] - hi); // hi converts back exactly; the remainder is exact in f32
+    }
+    {
+        const float hi = half_lo(pack_rtz(t, 0.0f));
+        w[15] = pack_rtz(hi, t - hi);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(w[i], w[4 + i], false, false);
+        w[i] = r0[0];
+        w[4 + i] = r0[1];
+        auto r1 = __builtin_amdgcn_permlane32_swap(w[8 + i], w[12 + i], false, false);
+        w[8 + i] = r1[0];
+        w[12 + i] = r1[1];
+    }
+    RayOperand op;
+    op.b[0][0] = __builtin_bit_cast(half8, (uint4v){w[0], w[1], w[2], w[3]});
+    op.b[1][0] = __builtin_bit_cast(half8, (uint4v){w[4], w[5], w[6], w[7]});
+    op.b[0][1] = __builtin_bit_cast(half8, (uint4v){w[8], w[9], w[10], w[11]});
+    op.b[1][1] = __builtin_bit_cast(half8, (uint4v){w[12], w[13], w[14], w[15]});
+    return op;
+}
+
+// The two 32x32 result tiles of table block `blk`: acc[rb] register v of lane l is sphere
+// 32 blk + (v & 3) + 8 (v >> 2) + 4 (l >> 5) against the ray of lane 32 rb + (l & 31).
+__device__ __forceinline__ void mfma_block(const uint4v *tab_lane, int blk, const RayOperand &op, float16v &acc0,
+                                           float16v &acc1) {
+    const half8 a0 = __builtin_bit_cast(half8, tab_lane[(2 * blk) * 64]);
+    const half8 a1 = __builtin_bit_cast(half8, tab_lane[(2 * blk + 1) * 64]);
+    const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, op.b[0][0], zero, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, op.b[1][0], zero, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, op.b[0][1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, op.b[1][1], acc1, 0, 0, 0);
+}
+
+// Sign bits of a result tile's sixteen registers, register v in bit v.
+__device__ __forceinline__ uint32_t sign_mask(const float16v &acc) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int v = 15; v >= 0; --v) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[v]), 31);
+    return m;
+}
+
+// Closest sphere hit of every lane's ray: the MFMA filter over the table in LDS, candidates through
+// the wave's queue (rt_device.h), the few spheres outside the table directly.  Whole wave; a lane
+// without a ray passes live = false.
+template <class F> // MfmaFrame, in whatever address space the launch parameters live
+__device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, V3 dh, bool live, float tmin,
+                                          int self_id, int lane, const CandQ &cq, const float4 *__restrict__ sph,
+                                          float &best_t, int &best_id) {
+    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
+    cq.slot[lane] = NO_HIT_KEY;
+    int count = 0; // queue fill, wave-uniform
+    const uint4v *tab_lane = tab + lane;
+    const int row_of_half = 4 * (lane >> 5);
+    const int col = lane & 31;
+#pragma unroll 1
+    for (int blk = 0; blk < fr.n_blocks; ++blk) {
+        float16v acc0, acc1;
+        mfma_block(tab_lane, blk, op, acc0, acc1);
+        uint32_t m = sign_mask(acc0) | (sign_mask(acc1) << 16);
+        // one (ray, sphere) pair per lane and turn, lowest register first
+        for (unsigned long long any = __ballot(m != 0); any != 0; any = __ballot(m != 0)) {
+            if (m != 0) {
+                const int bit = __builtin_ctz(m);
+                m &= m - 1;
+                const int v = bit & 15;
+                const int s = 32 * blk + (v & 3) + 8 * (v >> 2) + row_of_half;
+                const int owner = col | ((bit >> 4) << 5);
+                cq.ent[count + lane_rank(any)] = (unsigned)owner | ((unsigned)s << 6);
+            }
+            count += (int)__popcll(any);
+            while (count >= 64) resolve_batch(cq, count, 64, lane, o, dh, tmin, self_id, sph);
+        }
+    }
+    while (count > 0) resolve_batch(cq, count, min(count, 64), lane, o, dh, tmin, self_id, sph);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned long long key = cq.slot[lane];
+    const cptr<float4> csph = as_const(sph);
+    for (int i = 0; i < fr.n_big; ++i) {
+        const int s = fr.big[i];
+        const float4 sp = load_const4(csph, s); // same address in every lane: a scalar load
+        const float cand = sphere_root(o, dh, sp.x, sp.y, sp.z, sp.w * sp.w, tmin);
+        if (cand > tmin && cand < __builtin_inff() && s != self_id) {
+            const unsigned long long k = ((unsigned long long)__float_as_uint(cand) << 32) | (unsigned long long)(unsigned)s;
+            key = k < key ? k : key;
+        }
+    }
+    if (live && key != NO_HIT_KEY) {
+        best_t = __uint_as_float((unsigned)(key >> 32));
+        best_id = (int)(unsigned)key;
+    }
+}
+
+#endif // device code
+
+} // namespace rt

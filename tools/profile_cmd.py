@@ -27,6 +27,8 @@ PASSES = {
              "SQ_WAVES", "SQ_INSTS_BRANCH", "SQ_ACTIVE_INST_SCA", "GRBM_GUI_ACTIVE"],
     "lds": ["SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
             "SQ_LDS_ADDR_CONFLICT", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
+    "mfma": ["SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES",
+             "SQ_BUSY_CYCLES", "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE"],
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
 }
