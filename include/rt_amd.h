@@ -316,6 +316,28 @@ void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint
  * (src/Camera.cpp:84,129-130; inc/RTMaterial.h:72,111,158). */
 int rt_rng4_device_host(rt_ctx *ctx, int n, const uint32_t *h_keys, uint32_t *h_out);
 
+/* The sphere filter of the matrix-core scan, exposed for tests.  Scenes of more than 8 and up to about
+ * 1400 spheres are scanned by a conservative filter evaluated on the matrix cores (every sphere a ray
+ * could hit passes; what passes is decided exactly), in a frame centred on the sphere cloud; spheres much
+ * larger than the cloud are kept out of it and decided directly.  No counterpart in the reference: it is
+ * SceneManager::hitClosest's loop over all objects (src/RayTracer.cpp:77-82) in another arithmetic. */
+typedef struct rt_filter_info {
+    int32_t in_use;     /* 1 if renders of the uploaded scene (sphere-only, no lights) use this filter */
+    float center[3];    /* centre of the frame */
+    float radius;       /* its unit length: the radius of the sphere cloud */
+    float margin;       /* a sphere passes when disc / radius^2 + margin + margin_far * max|O'_i| > 0 */
+    float margin_far;   /*   (disc: discriminant of the unit-direction quadratic; O': origin in frame units) */
+    int32_t n_rows;     /* rows of the filter table (row = sphere index; padded to a multiple of 32) */
+    int32_t n_big;      /* spheres decided outside the filter ... */
+    int32_t big[8];     /* ... and their indices; their rows never pass */
+} rt_filter_info;
+int rt_filter_describe(rt_ctx *ctx, rt_filter_info *out);
+/* Filter values of n rays (origin, direction: 3 floats each, direction of any length) against every row,
+ * computed by the device code the render kernel runs: values[ray * n_rows + row], in frame units with
+ * the sign convention of the kernel (NEGATIVE = the sphere passes), i.e. an approximation of
+ * -(disc / radius^2 + margin + margin_far * max|O'_i|).  Host pointers, synchronous. */
+int rt_filter_values_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir, float *h_values);
+
 /* Library/ABI version (major*100 + minor). */
 int rt_version(void);
 

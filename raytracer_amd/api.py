@@ -84,12 +84,17 @@ class RenderParams:
 EXPORTS = [
     "rt_version", "rt_rng4", "rt_rng4_device_host", "rt_output_rows", "rt_create", "rt_destroy", "rt_last_error",
     "rt_upload_scene", "rt_upload_scene_ex", "rt_upload_lights", "rt_set_camera", "rt_render", "rt_render_noalloc",
-    "rt_render_host", "rt_last_kernel_ms", "rt_device_allocations",
+    "rt_render_host", "rt_last_kernel_ms", "rt_device_allocations", "rt_filter_describe", "rt_filter_values_host",
     "rt_group_create", "rt_group_destroy", "rt_group_last_error", "rt_group_size", "rt_group_transport",
     "rt_group_device_allocations", "rt_group_upload_scene_ex", "rt_group_upload_lights", "rt_group_set_camera",
     "rt_group_render", "rt_group_render_host",
     "rt_first_hit", "rt_first_hit_host", "rt_first_hit_ex", "rt_first_hit_ex_host", "rt_scatter_host",
 ]
+
+class _FilterInfo(C.Structure):
+    _fields_ = [("in_use", C.c_int32), ("center", C.c_float * 3), ("radius", C.c_float), ("margin", C.c_float),
+                ("margin_far", C.c_float), ("n_rows", C.c_int32), ("n_big", C.c_int32), ("big", C.c_int32 * 8)]
+
 
 _lib = None
 
@@ -119,6 +124,10 @@ def load_library(path: str | None = None) -> C.CDLL:
     _proto(lib, "rt_rng4", "restype", None)
     _proto(lib, "rt_rng4_device_host", "argtypes", [vp, C.c_int, vp, vp])
     _proto(lib, "rt_rng4_device_host", "restype", C.c_int)
+    _proto(lib, "rt_filter_describe", "argtypes", [vp, C.POINTER(_FilterInfo)])
+    _proto(lib, "rt_filter_describe", "restype", C.c_int)
+    _proto(lib, "rt_filter_values_host", "argtypes", [vp, C.c_int, vp, vp, vp])
+    _proto(lib, "rt_filter_values_host", "restype", C.c_int)
     _proto(lib, "rt_output_rows", "argtypes", [C.POINTER(_Params)])
     _proto(lib, "rt_output_rows", "restype", C.c_int)
     _proto(lib, "rt_create", "argtypes", [C.c_int, C.POINTER(vp)])
@@ -317,6 +326,23 @@ class Renderer:
         keys = np.ascontiguousarray(keys, dtype=np.uint32).reshape(-1, 4)
         out = np.zeros_like(keys)
         self._check(self.lib.rt_rng4_device_host(self.h, len(keys), _ptr(keys), _ptr(out)), "rt_rng4_device_host")
+        return out
+
+    def filter_describe(self) -> dict:
+        """Frame and membership of the matrix-core sphere filter of the uploaded scene (n_rows == 0: none)."""
+        fi = _FilterInfo()
+        self._check(self.lib.rt_filter_describe(self.h, C.byref(fi)), "rt_filter_describe")
+        return {"in_use": bool(fi.in_use), "center": np.array(list(fi.center), dtype=np.float32), "radius": float(fi.radius),
+                "margin": float(fi.margin), "margin_far": float(fi.margin_far), "n_rows": int(fi.n_rows),
+                "big": [int(fi.big[i]) for i in range(fi.n_big)]}
+
+    def filter_values(self, org: np.ndarray, dir: np.ndarray) -> np.ndarray:
+        """Device-evaluated filter values [n_rays, n_rows]; negative = the sphere of that row passes."""
+        org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(org), self.filter_describe()["n_rows"]), dtype=np.float32)
+        self._check(self.lib.rt_filter_values_host(self.h, len(org), _ptr(org), _ptr(dir), _ptr(out)),
+                    "rt_filter_values_host")
         return out
 
     def last_kernel_ms(self) -> float:

@@ -349,25 +349,18 @@ __global__ __launch_bounds__(wg_threads_of(SRC), SRC == SRC_MFMA ? 4 : (FULL ? 1
     }
     if (SRC == SRC_MFMA) {
         uint4v *dst = reinterpret_cast<uint4v *>(smem + wave_state_bytes_of(SRC));
-        for (int i = threadIdx.x; i < KP.mf.n_blocks * MF_BLOCK_WORDS; i += WGT) dst[i] = KS.mf_table[i];
+        for (int i = threadIdx.x; i < (KP.mf.n_blocks + 1) * MF_BLOCK_WORDS; i += WGT) dst[i] = KS.mf_table[i];
     }
     __syncthreads();
 
-#ifdef RT_SECTIONS
-    // tuning build: shader cycles this wave spends in each part of the loop body
-    unsigned long long sec_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long sec_last = __builtin_amdgcn_s_memtime();
-    int sec_cur = 7;
-#define RT_SEC(k)                                                     \
-    do {                                                              \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        sec_t[sec_cur] += now_ - sec_last;                            \
-        sec_last = now_;                                              \
-        sec_cur = (k);                                                \
+    // tuning build (-DRT_SECTIONS): shader cycles this wave spends in each part of the loop body.  Not in the
+    // scalar-load variant: a time stamp lands in SGPRs that its loads in flight own.
+    SecClock sec;
+    sec.start();
+#define RT_SEC(k)                          \
+    do {                                   \
+        if (SRC != SRC_SCALAR) sec.mark(k); \
     } while (0)
-#else
-#define RT_SEC(k)
-#endif
 #ifdef RT_STATS
     const unsigned long long t_start = wall_clock64();
     unsigned long long t_fetch[2] = {t_start, t_start};
@@ -443,7 +436,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC), SRC == SRC_MFMA ? 4 : (FULL ? 1
         } else if (SRC == SRC_LDS_RESIDENT) {
             if (active) scan_lds(lds_sph, lds_r2, nquads, 0, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
         } else if (SRC == SRC_MFMA) {
-            scan_mfma(lds_tab, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph, best_t, best_id);
+            scan_mfma(lds_tab, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph, best_t, best_id, sec);
         } else {
             // the whole wave scans: a lane without a ray passes no filter
             rk.thr = active ? rk.thr : __builtin_inff();
@@ -726,8 +719,8 @@ __global__ __launch_bounds__(wg_threads_of(SRC), SRC == SRC_MFMA ? 4 : (FULL ? 1
     }
 #ifdef RT_SECTIONS
     RT_SEC(7);
-    if (lane == 0)
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_sections[k], sec_t[k]);
+    if (lane == 0 && SRC != SRC_SCALAR)
+        for (int k = 0; k < 16; ++k) atomicAdd(&g_sections[k], sec.t[k]);
 #endif
 #ifdef RT_STATS
     if (lane == 0 && items_done > 0) {
@@ -752,6 +745,36 @@ __global__ __launch_bounds__(wg_threads_of(SRC), SRC == SRC_MFMA ? 4 : (FULL ? 1
 #undef accum
 #undef rays_out
 #undef queue
+}
+
+// Filter values of a batch of rays against every table row, through the device functions of the render
+// kernel's scan (test hook).  One wave per 64 rays; the table words come from global memory here.
+__global__ __launch_bounds__(64) void filter_probe_kernel(int n_rays, const float *__restrict__ org,
+                                                          const float *__restrict__ dir, const uint4v *__restrict__ tab,
+                                                          MfmaFrame fr, float *__restrict__ out) {
+    const int lane = threadIdx.x, base = blockIdx.x * 64, i = base + lane;
+    const bool live = i < n_rays;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    if (live) {
+        o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+        d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    }
+    const V3 dh = d * __frsqrt_rn(dot(d, d)); // as set_dir() does
+    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
+    const int n_rows = fr.n_blocks * MF_BLOCK;
+    for (int blk = 0; blk < fr.n_blocks; ++blk) {
+        const half8 a0 = __builtin_bit_cast(half8, tab[(2 * blk) * 64 + lane]);
+        const half8 a1 = __builtin_bit_cast(half8, tab[(2 * blk + 1) * 64 + lane]);
+        const float16v acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
+        const float16v acc1 = mfma_tile(a0, a1, op.b[1][0], op.b[1][1]);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = MF_BLOCK * blk + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+            const int r0 = base + (lane & 31), r1 = r0 + 32;
+            if (r0 < n_rays) out[(size_t)r0 * n_rows + row] = acc0[v] * (1.0f / (MF_SCALE * MF_SCALE));
+            if (r1 < n_rays) out[(size_t)r1 * n_rows + row] = acc1[v] * (1.0f / (MF_SCALE * MF_SCALE));
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1184,7 +1207,6 @@ struct rt_ctx {
     MfmaFrame mf{};
     bool mf_usable = false;  // the scene has a table and it fits in LDS
     bool mf_wanted = true;   // RT_AMD_SPHERE_SOURCE did not ask for another source
-    int mf_wgs_per_cu = 1;   // resident workgroups of the matrix-core kernel per CU (set at the first launch)
     unsigned char *d_queue = nullptr; // ring of work-item counters of the persistent render kernel
     unsigned queue_next = 0;          // next slot of the ring
     unsigned char *d_scratch = nullptr; // this device's copy of `scratch` (rt_render_noalloc)
@@ -1291,7 +1313,7 @@ int local_strips(const rt_params *p) {
 extern "C" __attribute__((visibility("default"))) int rt_debug_sections(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sections), sizeof(g_sections)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_sections), z, sizeof z) != hipSuccess) return -1;
     }
     return 0;
@@ -1330,6 +1352,47 @@ RT_API int rt_rng4_device_host(rt_ctx *ctx, int n, const uint32_t *h_keys, uint3
                        (const uint32_t *)ctx->fh_org, (uint32_t *)ctx->fh_dir);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->fh_dir, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+RT_API int rt_filter_describe(rt_ctx *ctx, rt_filter_info *out) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!out) return fail(ctx, RT_ERR_INVALID, "out is null");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    memset(out, 0, sizeof *out);
+    if (!ctx->mf_usable) return RT_OK;
+    out->in_use = ctx->mf_wanted ? 1 : 0;
+    out->center[0] = ctx->mf.cx;
+    out->center[1] = ctx->mf.cy;
+    out->center[2] = ctx->mf.cz;
+    out->radius = MF_SCALE / ctx->mf.scale;
+    out->margin = MF_MARGIN;
+    out->margin_far = MF_MARGIN_FAR;
+    out->n_rows = ctx->mf.n_blocks * MF_BLOCK;
+    out->n_big = ctx->mf.n_big;
+    for (int i = 0; i < ctx->mf.n_big; ++i) out->big[i] = ctx->mf.big[i];
+    return RT_OK;
+}
+
+RT_API int rt_filter_values_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir, float *h_values) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (!ctx->mf_usable) return fail(ctx, RT_ERR_UNSUPPORTED, "the uploaded scene has no filter table");
+    if (n_rays < 0 || (n_rays > 0 && (!h_org || !h_dir || !h_values))) return fail(ctx, RT_ERR_INVALID, "bad ray / value array");
+    if (n_rays == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t rb = (size_t)n_rays * 12, vb = (size_t)n_rays * (size_t)ctx->mf.n_blocks * MF_BLOCK * 4;
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_org, rb));
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_dir, rb));
+    HIP_TRY(ctx, reserve(ctx, &ctx->fh_nrm, vb));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->fh_org, h_org, rb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->fh_dir, h_dir, rb, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(filter_probe_kernel, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, ctx->stream, n_rays,
+                       (const float *)ctx->fh_org, (const float *)ctx->fh_dir, (const uint4v *)ctx->d_mf_table, ctx->mf,
+                       (float *)ctx->fh_nrm);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(h_values, ctx->fh_nrm, vb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -1529,8 +1592,9 @@ MfTable build_mf_table(const std::vector<float4> &sph) {
     T.fr.scale = scale;
     T.fr.n_blocks = n_blocks;
     T.fr.n_big = n_big;
-    T.words.assign((size_t)n_blocks * MF_BLOCK_WORDS * 4, 0u);
-    for (int row = 0; row < n_blocks * MF_BLOCK; ++row) {
+    // one spare block of rows that never pass follows the list: the scan reads one block ahead
+    T.words.assign((size_t)(n_blocks + 1) * MF_BLOCK_WORDS * 4, 0u);
+    for (int row = 0; row < (n_blocks + 1) * MF_BLOCK; ++row) {
         uint16_t hi[9] = {0}, lo[9] = {0}, q_hi = half_rn(MF_NEVER), q_lo = 0;
         const uint16_t unit = half_rn(-MF_SCALE);
         if (row < n && !big[row]) {
@@ -1821,7 +1885,7 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
         // matrix-core filter: one table per workgroup in LDS, as many workgroups as stay resident
         src = SRC_MFMA;
         k.mf = ctx->mf;
-        lds = wave_state_bytes_of(SRC_MFMA) + (size_t)ctx->mf.n_blocks * MF_BLOCK_WORDS * 16;
+        lds = wave_state_bytes_of(SRC_MFMA) + (size_t)(ctx->mf.n_blocks + 1) * MF_BLOCK_WORDS * 16;
         int resident = 0;
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
                          &resident, reinterpret_cast<const void *>(&render_kernel<SRC_MFMA, false>),

@@ -156,8 +156,30 @@ __device__ __forceinline__ f2 pair_filter(const RayK &r, float4 A, float4 B) {
     return __builtin_elementwise_fma(cz, r.kz, __builtin_elementwise_fma(cy, r.ky, __builtin_elementwise_fma(cx, r.kx, t)));
 }
 
+// Tuning build only (-DRT_SECTIONS): wave cycles per part of the render loop, from s_memtime stamps.
 #ifdef RT_SECTIONS
-__device__ unsigned long long g_sections[8]; // tuning build only: wave cycles per part of the render loop
+__device__ unsigned long long g_sections[16];
+struct SecClock {
+    unsigned long long t[16];
+    unsigned long long last;
+    int cur;
+    __device__ __forceinline__ void start() {
+        for (int k = 0; k < 16; ++k) t[k] = 0;
+        last = __builtin_amdgcn_s_memtime();
+        cur = 7;
+    }
+    __device__ __forceinline__ void mark(int k) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        t[cur] += now - last;
+        last = now;
+        cur = k;
+    }
+};
+#else
+struct SecClock {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+};
 #endif
 #ifdef RT_STATS
 // tuning build only: wave-level event counters

@@ -127,25 +127,32 @@ __device__ __forceinline__ RayOperand mfma_ray_operand(V3 o, V3 dh, bool live, f
     return op;
 }
 
-// The two 32x32 result tiles of table block `blk`: acc[rb] register v of lane l is sphere
-// 32 blk + (v & 3) + 8 (v >> 2) + 4 (l >> 5) against the ray of lane 32 rb + (l & 31).
-__device__ __forceinline__ void mfma_block(const uint4v *tab_lane, int blk, const RayOperand &op, float16v &acc0,
-                                           float16v &acc1) {
-    const half8 a0 = __builtin_bit_cast(half8, tab_lane[(2 * blk) * 64]);
-    const half8 a1 = __builtin_bit_cast(half8, tab_lane[(2 * blk + 1) * 64]);
+// One 32x32 result tile: register v of lane l is sphere (v & 3) + 8 (v >> 2) + 4 (l >> 5) of the table
+// block behind (a0, a1) against the ray of lane l & 31 of the ray half behind (b0, b1).
+__device__ __forceinline__ float16v mfma_tile(half8 a0, half8 a1, half8 b0, half8 b1) {
     const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, op.b[0][0], zero, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, op.b[1][0], zero, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, op.b[0][1], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, op.b[1][1], acc1, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, zero, 0, 0, 0), 0, 0, 0);
 }
 
-// Sign bits of a result tile's sixteen registers, register v in bit v.
-__device__ __forceinline__ uint32_t sign_mask(const float16v &acc) {
-    uint32_t m = 0;
+// Sign bits of a result tile, register v in bit v.  On this chip every vector instruction holds the
+// issue port for about four cycles, so what counts is their number: gathering the signs takes one
+// v_alignbit_b32 per register, OR-ing the registers half as many instructions (v_or3_b32), and a ray
+// passes the filter for about one sphere in three hundred: more than half of the blocks pass for no
+// lane of the wave and are never gathered.
+__device__ __forceinline__ uint32_t or16(const float16v &acc) {
+    uint32_t any = 0;
 #pragma unroll
-    for (int v = 15; v >= 0; --v) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[v]), 31);
-    return m;
+    for (int v = 0; v < 16; ++v) any |= __float_as_uint(acc[v]);
+    return any;
+}
+__device__ __forceinline__ uint32_t gather16(const float16v &acc) {
+    uint32_t lo = 0, hi = 0; // two chains: dependent instructions are not back to back
+#pragma unroll
+    for (int v = 7; v >= 0; --v) {
+        lo = __builtin_amdgcn_alignbit(lo, __float_as_uint(acc[v]), 31);
+        hi = __builtin_amdgcn_alignbit(hi, __float_as_uint(acc[8 + v]), 31);
+    }
+    return lo | (hi << 8);
 }
 
 // Closest sphere hit of every lane's ray: the MFMA filter over the table in LDS, candidates through
@@ -154,19 +161,34 @@ __device__ __forceinline__ uint32_t sign_mask(const float16v &acc) {
 template <class F> // MfmaFrame, in whatever address space the launch parameters live
 __device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, V3 dh, bool live, float tmin,
                                           int self_id, int lane, const CandQ &cq, const float4 *__restrict__ sph,
-                                          float &best_t, int &best_id) {
+                                          float &best_t, int &best_id, SecClock &sec) {
     const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
     cq.slot[lane] = NO_HIT_KEY;
     int count = 0; // queue fill, wave-uniform
     const uint4v *tab_lane = tab + lane;
     const int row_of_half = 4 * (lane >> 5);
     const int col = lane & 31;
+    // Software pipeline: the matrix pipe works on one ray half's tile while the signs of the other's are
+    // gathered, and the table words of the next block are on their way from LDS meanwhile (the table is
+    // followed by one spare block, so the read-ahead stays inside it).
+    sec.mark(8); // tuning build: 8 = matrix products and sign masks, 9 = recording, 10 = decisions, 11 = the rest
+    half8 a0 = __builtin_bit_cast(half8, tab_lane[0]), a1 = __builtin_bit_cast(half8, tab_lane[64]);
+    float16v acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
 #pragma unroll 1
     for (int blk = 0; blk < fr.n_blocks; ++blk) {
-        float16v acc0, acc1;
-        mfma_block(tab_lane, blk, op, acc0, acc1);
-        uint32_t m = sign_mask(acc0) | (sign_mask(acc1) << 16);
+        const float16v acc1 = mfma_tile(a0, a1, op.b[1][0], op.b[1][1]);
+        a0 = __builtin_bit_cast(half8, tab_lane[(2 * blk + 2) * 64]);
+        a1 = __builtin_bit_cast(half8, tab_lane[(2 * blk + 3) * 64]);
+        // the masks must be taken before acc0's registers are given to the next block's products
+        // one test per block: does any lane have a negative among its 32 results?  (Measured: tests
+        // per group of eight registers save instructions and lose as much to their branches.)
+        const bool some = __ballot((int)(or16(acc0) | or16(acc1)) < 0) != 0;
+        uint32_t m = 0;
+        if (some) m = gather16(acc0) | (gather16(acc1) << 16);
+        acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
+        sec.mark(9);
         // one (ray, sphere) pair per lane and turn, lowest register first
+        if (some)
         for (unsigned long long any = __ballot(m != 0); any != 0; any = __ballot(m != 0)) {
             if (m != 0) {
                 const int bit = __builtin_ctz(m);
@@ -177,10 +199,18 @@ __device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, 
                 cq.ent[count + lane_rank(any)] = (unsigned)owner | ((unsigned)s << 6);
             }
             count += (int)__popcll(any);
-            while (count >= 64) resolve_batch(cq, count, 64, lane, o, dh, tmin, self_id, sph);
+            if (count >= 64) {
+                sec.mark(10);
+                do resolve_batch(cq, count, 64, lane, o, dh, tmin, self_id, sph);
+                while (count >= 64);
+                sec.mark(9);
+            }
         }
+        sec.mark(8);
     }
+    sec.mark(10);
     while (count > 0) resolve_batch(cq, count, min(count, 64), lane, o, dh, tmin, self_id, sph);
+    sec.mark(11);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     unsigned long long key = cq.slot[lane];
     const cptr<float4> csph = as_const(sph);

@@ -1,0 +1,133 @@
+"""The matrix-core sphere filter against a double-precision evaluation of the same quantity.
+
+The scan of scenes with more than 8 spheres evaluates, per (ray, sphere), a conservative filter on the
+matrix cores and decides exactly only what passes.  A frame can only be right if the filter never drops
+a sphere the ray's line meets; these tests check that property and the size of its error directly, on
+the values the device code of the render kernel computes (rt_filter_values_host).  The reference has no
+counterpart of the filter itself: it tests every sphere exactly (src/RayTracer.cpp:77-82,
+inc/RTObjects.h:135-149)."""
+import numpy as np
+import pytest
+
+from raytracer_amd import Renderer, RenderParams, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _xyzr(scene):
+    sp = scene.spheres
+    return np.stack([sp["cx"], sp["cy"], sp["cz"], sp["r"]], axis=1).astype(np.float64)
+
+
+def _rays(scene, n, rng, spread):
+    """Origins: around the cloud, far from it, and exactly on sphere surfaces; directions: anywhere, at
+    sphere centres, and grazing sphere rims."""
+    c = _xyzr(scene)[:, :3]
+    r = np.abs(_xyzr(scene)[:, 3])
+    small = r < 50
+    org = rng.normal(size=(n, 3)) * spread
+    far = rng.random(n) < 0.15
+    org[far] *= 60.0
+    on = rng.random(n) < 0.3
+    k = rng.integers(0, len(c), n)
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    org[on] = c[k[on]] + u[on] * r[k[on], None]
+    d = rng.normal(size=(n, 3))
+    aim = rng.random(n) < 0.6
+    t = rng.integers(0, int(small.sum()), n)
+    cs, rs = c[small][t], r[small][t]
+    w = rng.normal(size=(n, 3))
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    graze = rng.random(n) < 0.5
+    target = cs + w * (rs * np.where(graze, 1.0 + rng.normal(size=n) * 1e-4, rng.random(n)))[:, None]
+    d[aim] = (target - org)[aim]
+    d *= (0.1 + 5.0 * rng.random(n))[:, None]  # unnormalised, as scattered rays are
+    return org.astype(np.float32), d.astype(np.float32)
+
+
+def _exact(scene, info, org, d):
+    """disc / radius^2 for every (ray, sphere) in double, from the float inputs the device sees."""
+    o = org.astype(np.float64)
+    dd = d.astype(np.float64)
+    # the unit direction the kernel uses is a float; its error is part of what the margin must cover
+    dh = dd / np.linalg.norm(dd, axis=1, keepdims=True)
+    c = _xyzr(scene)[:, :3]
+    r = _xyzr(scene)[:, 3]
+    oc = o[:, None, :] - c[None, :, :]
+    hb = np.einsum("rsk,rk->rs", oc, dh)
+    perp2 = np.einsum("rsk,rsk->rs", oc, oc) - hb * hb
+    disc = r[None, :] ** 2 - perp2
+    R = float(info["radius"])
+    oprime = (o - info["center"].astype(np.float64)[None, :]) / R
+    m_ray = info["margin"] + info["margin_far"] * np.abs(oprime).max(axis=1)
+    p = oprime - dh * np.einsum("rk,rk->r", oprime, dh)[:, None]
+    return disc / (R * R), m_ray, np.linalg.norm(p, axis=1)
+
+
+@pytest.mark.parametrize("name", ["random_spheres", "grid30"])
+def test_filter_is_a_superset_and_its_error_is_within_the_margin(name):
+    scene = scenes.by_name(name)
+    rng = np.random.default_rng(7)
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        info = r.filter_describe()
+        assert info["in_use"] and info["n_rows"] >= len(scene.spheres)
+        org, d = _rays(scene, 4096, rng, spread=info["radius"])
+        vals = r.filter_values(org, d).astype(np.float64)
+    F, m_ray, pnorm = _exact(scene, info, org, d)
+    n = len(scene.spheres)
+    table = np.ones(n, dtype=bool)
+    table[info["big"]] = False
+    # rows of spheres outside the table, and the padding, never pass
+    assert (vals[:, ~np.pad(table, (0, vals.shape[1] - n))] > 0).all()
+    v = vals[:, :n][:, table]
+    Ft = F[:, table]
+    # 1. no sphere the line meets is dropped (the exact decision may also accept a discriminant that
+    #    rounding made barely negative: allow for 1e-6 of the sphere's size, far inside the margin)
+    meets = Ft >= -1e-6 * (np.abs(_xyzr(scene)[table, 3]) / info["radius"]) ** 2
+    assert (v[meets] < 0).all(), f"{(v[meets] >= 0).sum()} hits dropped"
+    # 2. the value is -(disc/R^2 + margin) to within half the margin, for lines that reach the cloud
+    near = pnorm <= 1.0
+    err = (np.abs(v + (Ft + m_ray[:, None])) / m_ray[:, None])[near]
+    print(f"{name}: {meets.sum()} line-sphere meetings, largest error {err.max():.3f} of the ray's margin "
+          f"(margin {info['margin']:.3e}), passing {100.0 * (v < 0).mean():.3f} % vs meeting {100.0 * (Ft >= 0).mean():.3f} %")
+    assert err.max() <= 0.5
+    # 3. a line that passes the whole cloud by meets nothing and passes nothing
+    away = pnorm > 1.01
+    assert not meets[away].any()
+    assert (v[away] > 0).all()
+
+
+def test_scenes_without_a_table_say_so():
+    with Renderer(0) as r:
+        r.set_scene(scenes.by_name("small"))  # four spheres: decided directly
+        assert r.filter_describe()["n_rows"] == 0
+
+
+def test_big_spheres_are_kept_out_of_the_frame():
+    scene = scenes.by_name("random_spheres")
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        info = r.filter_describe()
+    ground = int(np.argmax(np.abs(_xyzr(scene)[:, 3])))
+    assert info["big"] == [ground]
+    assert info["radius"] < 30.0  # the cloud of the small spheres, not the r = 1000 ground
+
+
+def test_frames_are_the_same_bytes_with_either_filter(monkeypatch):
+    """The filter only selects what the exact decision sees: scalar-load packed-FP32 filter and
+    matrix-core filter render the same bytes and count the same rays."""
+    scene = scenes.by_name("random_spheres")
+    p = RenderParams(192, 108, 24, 50, seed=11)
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        assert r.filter_describe()["in_use"]
+        a = r.render_host(p, want_accum=True)
+    monkeypatch.setenv("RT_AMD_SPHERE_SOURCE", "scalar")
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        assert not r.filter_describe()["in_use"]
+        b = r.render_host(p, want_accum=True)
+    assert a[2] == b[2]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
