@@ -52,14 +52,18 @@ constexpr size_t CQ_BYTES = WAVES_PER_WG * (CAND_CAP * sizeof(unsigned) + 64 * s
 constexpr size_t WAVE_STATE_BYTES = ACC_BYTES + CQ_BYTES;
 
 // Where the scan loop takes the sphere words from.
-enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2, SRC_MFMA = 3 };
+enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2, SRC_MFMA = 3, SRC_MFMA_STREAMED = 4 };
+constexpr bool is_mfma(int src) { return src == SRC_MFMA || src == SRC_MFMA_STREAMED; }
 
 // The matrix-core variant shares one filter table per workgroup, so its workgroups are as large as
 // they come (16 waves: one workgroup per CU at four waves per SIMD), and its queue only ever holds
 // the remainder of one batch plus one turn of the recording loop.
-constexpr size_t MF_LDS_BYTES = 160 * 1024; // LDS of one CU: what a workgroup of the matrix-core variant may use
-constexpr int wg_threads_of(int src) { return src == SRC_MFMA ? 1024 : WG_THREADS; }
-constexpr int cand_cap_of(int src) { return src == SRC_MFMA ? 128 : CAND_CAP; }
+constexpr size_t MF_LDS_BYTES = 159 * 1024; // dynamic LDS a workgroup of the matrix-core variants may use: a CU has 160 KiB, and the workgroup-wide vote of the streamed variant keeps a little static LDS
+#ifndef RT_MF_STREAM_THREADS
+#define RT_MF_STREAM_THREADS 1024
+#endif
+constexpr int wg_threads_of(int src) { return src == SRC_MFMA ? 1024 : src == SRC_MFMA_STREAMED ? RT_MF_STREAM_THREADS : WG_THREADS; }
+constexpr int cand_cap_of(int src) { return is_mfma(src) ? 128 : CAND_CAP; }
 constexpr size_t acc_bytes_of(int src) { return (size_t)(wg_threads_of(src) / 64) * WAVE_LDS_WORDS * sizeof(unsigned long long); }
 constexpr size_t wave_state_bytes_of(int src) {
     return acc_bytes_of(src) + (size_t)(wg_threads_of(src) / 64) * (cand_cap_of(src) * sizeof(unsigned) + 64 * sizeof(unsigned long long));
@@ -310,7 +314,7 @@ __device__ __forceinline__ Tile decode_item(const P &p, unsigned item) {
 // short.  Inside a tile the wave runs the path loop described at the top of this file.
 template <int SRC, bool FULL>
 // the sphere-only variants are held to the register budget of five waves per SIMD
-__global__ __launch_bounds__(wg_threads_of(SRC), SRC == SRC_MFMA ? 4 : (FULL ? 1 : 5)) void render_kernel(KArgs args) {
+__global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? 1 : 5)) void render_kernel(KArgs args) {
     constexpr int WGT = wg_threads_of(SRC), NW = WGT / 64;
     // The scan needs 64 SGPRs for sphere words, so whatever else lives in SGPRs across it is spilled
     // into VGPR lanes and comes back through v_readlane, which costs VALU issue slots, the kernel's
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC), SRC == SRC_MFMA ? 4 : (FULL ? 1
     // descriptors), then the sphere words
     unsigned long long *acc_all = reinterpret_cast<unsigned long long *>(smem);
     float4 *lds_sph = reinterpret_cast<float4 *>(smem + wave_state_bytes_of(SRC));
-    const uint4v *lds_tab = reinterpret_cast<const uint4v *>(smem + wave_state_bytes_of(SRC)); // SRC_MFMA
+    uint4v *lds_tab = reinterpret_cast<uint4v *>(smem + wave_state_bytes_of(SRC)); // the matrix-core variants' table / tiles
     // the squared radii follow the pair words of the resident list / of one streamed tile
     float4 *lds_r2 = lds_sph + 4 * (SRC == SRC_LDS_STREAMED ? STREAM_QUADS : KP.n_quads);
 
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC), SRC == SRC_MFMA ? 4 : (FULL ? 1
 
     for (;;) {
         const bool wave_live = have0 || have1 || !queue_empty;
-        if (SRC == SRC_LDS_STREAMED) {
+        if (SRC == SRC_LDS_STREAMED || SRC == SRC_MFMA_STREAMED) {
             if (!__syncthreads_or(wave_live)) break;
         } else {
             if (!wave_live) break;
@@ -437,6 +441,9 @@ __global__ __launch_bounds__(wg_threads_of(SRC), SRC == SRC_MFMA ? 4 : (FULL ? 1
             if (active) scan_lds(lds_sph, lds_r2, nquads, 0, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
         } else if (SRC == SRC_MFMA) {
             scan_mfma(lds_tab, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph, best_t, best_id, sec);
+        } else if (SRC == SRC_MFMA_STREAMED) {
+            scan_mfma_streamed<WGT>(lds_tab, KS.mf_table, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph,
+                                    best_t, best_id, sec);
         } else {
             // the whole wave scans: a lane without a ray passes no filter
             rk.thr = active ? rk.thr : __builtin_inff();
@@ -1433,6 +1440,11 @@ RT_API int rt_create(int device, rt_ctx **out) {
         (void)hipGetLastError();
         ctx->mf_wanted = false;
     }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_MFMA_STREAMED, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)MF_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->mf_wanted = false;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cus = prop.multiProcessorCount;
@@ -1533,6 +1545,11 @@ struct MfTable {
     bool ok = false;
 };
 
+// LDS the matrix-core variants need: the whole table (plus the block the read-ahead touches), or two tiles
+size_t mf_lds_resident(int n_blocks) { return wave_state_bytes_of(SRC_MFMA) + (size_t)(n_blocks + 1) * MF_BLOCK_WORDS * 16; }
+constexpr size_t MF_LDS_STREAMED = wave_state_bytes_of(SRC_MFMA_STREAMED) + 2 * (size_t)MF_TILE_WORDS * 16;
+static_assert(MF_LDS_STREAMED <= MF_LDS_BYTES, "two tiles and the wave state fit in LDS");
+
 MfTable build_mf_table(const std::vector<float4> &sph) {
     MfTable T;
     memset(&T.fr, 0, sizeof T.fr);
@@ -1587,7 +1604,9 @@ MfTable build_mf_table(const std::vector<float4> &sph) {
     // the kernel computes O' = (O - c0) * scale in float: the table follows those floats exactly
     const float c0f[3] = {(float)c0[0], (float)c0[1], (float)c0[2]};
     const double inv_rs = (double)scale / (double)MF_SCALE;
-    const int n_blocks = (n + MF_BLOCK - 1) / MF_BLOCK;
+    int n_blocks = (n + MF_BLOCK - 1) / MF_BLOCK;
+    // a table that does not fit in LDS is streamed through it in whole tiles
+    if (mf_lds_resident(n_blocks) > MF_LDS_BYTES) n_blocks = (n_blocks + MF_TILE_BLOCKS - 1) / MF_TILE_BLOCKS * MF_TILE_BLOCKS;
     T.fr.cx = c0f[0]; T.fr.cy = c0f[1]; T.fr.cz = c0f[2];
     T.fr.scale = scale;
     T.fr.n_blocks = n_blocks;
@@ -1725,7 +1744,7 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
     if ((rc = to_device(ctx, &ctx->d_r2q, r2q)) != RT_OK) return rc;
     MfTable mft = build_mf_table(sph);
     ctx->mf_usable = false;
-    if (mft.ok && wave_state_bytes_of(SRC_MFMA) + mft.words.size() * 4 <= MF_LDS_BYTES) {
+    if (mft.ok) {
         HIP_TRY(ctx, reserve(ctx, (void **)&ctx->d_mf_table, mft.words.size() * 4));
         HIP_TRY(ctx, hipMemcpy(ctx->d_mf_table, mft.words.data(), mft.words.size() * 4, hipMemcpyHostToDevice));
         ctx->mf = mft.fr;
@@ -1883,25 +1902,29 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
     }
     if (ctx->mf_usable && ctx->mf_wanted && !full) {
         // matrix-core filter: one table per workgroup in LDS, as many workgroups as stay resident
-        src = SRC_MFMA;
+        const bool fits = mf_lds_resident(ctx->mf.n_blocks) <= MF_LDS_BYTES;
+        src = fits ? SRC_MFMA : SRC_MFMA_STREAMED;
         k.mf = ctx->mf;
-        lds = wave_state_bytes_of(SRC_MFMA) + (size_t)(ctx->mf.n_blocks + 1) * MF_BLOCK_WORDS * 16;
+        lds = fits ? mf_lds_resident(ctx->mf.n_blocks) : MF_LDS_STREAMED;
         int resident = 0;
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                         &resident, reinterpret_cast<const void *>(&render_kernel<SRC_MFMA, false>),
-                         wg_threads_of(SRC_MFMA), lds));
+                         &resident,
+                         fits ? reinterpret_cast<const void *>(&render_kernel<SRC_MFMA, false>)
+                              : reinterpret_cast<const void *>(&render_kernel<SRC_MFMA_STREAMED, false>),
+                         wg_threads_of(src), lds));
         if (resident < 1) return fail(ctx, RT_ERR_HIP, "the matrix-core render kernel does not fit on a CU");
-        const int wpw = wg_threads_of(SRC_MFMA) / 64;
+        const int wpw = wg_threads_of(src) / 64;
         want = (items + wpw - 1) / wpw;
         cap = (long long)ctx->n_cus * resident;
         grid = dim3((unsigned)(want < cap ? want : cap));
-        block = dim3(wg_threads_of(SRC_MFMA));
+        block = dim3(wg_threads_of(src));
     } else {
         memset(&k.mf, 0, sizeof k.mf);
     }
     const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, queue};
 #define RT_LAUNCH(S, L) hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, ka)
     if (src == SRC_MFMA) RT_LAUNCH(SRC_MFMA, false);
+    else if (src == SRC_MFMA_STREAMED) RT_LAUNCH(SRC_MFMA_STREAMED, false);
     else if (src == SRC_SCALAR) { if (full) RT_LAUNCH(SRC_SCALAR, true); else RT_LAUNCH(SRC_SCALAR, false); }
     else if (src == SRC_LDS_RESIDENT) { if (full) RT_LAUNCH(SRC_LDS_RESIDENT, true); else RT_LAUNCH(SRC_LDS_RESIDENT, false); }
     else { if (full) RT_LAUNCH(SRC_LDS_STREAMED, true); else RT_LAUNCH(SRC_LDS_STREAMED, false); }

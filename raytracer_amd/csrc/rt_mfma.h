@@ -155,46 +155,39 @@ __device__ __forceinline__ uint32_t gather16(const float16v &acc) {
     return lo | (hi << 8);
 }
 
-// Closest sphere hit of every lane's ray: the MFMA filter over the table in LDS, candidates through
-// the wave's queue (rt_device.h), the few spheres outside the table directly.  Whole wave; a lane
-// without a ray passes live = false.
-template <class F> // MfmaFrame, in whatever address space the launch parameters live
-__device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, V3 dh, bool live, float tmin,
-                                          int self_id, int lane, const CandQ &cq, const float4 *__restrict__ sph,
-                                          float &best_t, int &best_id, SecClock &sec) {
-    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
-    cq.slot[lane] = NO_HIT_KEY;
-    int count = 0; // queue fill, wave-uniform
-    const uint4v *tab_lane = tab + lane;
+// Filter of `nblk` table blocks at `tab_lane` (LDS, this lane's words; block b of the run is table block
+// blk0 + b) against the wave's rays; what passes goes through the queue.  The run is followed by one more
+// readable block (its content does not matter).
+// Software pipeline: the matrix pipe works on one ray half's tile while the other's is examined, and the
+// table words of the next block are on their way from LDS meanwhile.
+__device__ __forceinline__ void mfma_scan_blocks(const uint4v *tab_lane, int blk0, int nblk, const RayOperand &op,
+                                                 const CandQ &cq, int &count, int lane, V3 o, V3 dh, float tmin,
+                                                 int self_id, const float4 *__restrict__ sph, SecClock &sec) {
     const int row_of_half = 4 * (lane >> 5);
     const int col = lane & 31;
-    // Software pipeline: the matrix pipe works on one ray half's tile while the signs of the other's are
-    // gathered, and the table words of the next block are on their way from LDS meanwhile (the table is
-    // followed by one spare block, so the read-ahead stays inside it).
-    sec.mark(8); // tuning build: 8 = matrix products and sign masks, 9 = recording, 10 = decisions, 11 = the rest
     half8 a0 = __builtin_bit_cast(half8, tab_lane[0]), a1 = __builtin_bit_cast(half8, tab_lane[64]);
     float16v acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
 #pragma unroll 1
-    for (int blk = 0; blk < fr.n_blocks; ++blk) {
+    for (int blk = 0; blk < nblk; ++blk) {
         const float16v acc1 = mfma_tile(a0, a1, op.b[1][0], op.b[1][1]);
         a0 = __builtin_bit_cast(half8, tab_lane[(2 * blk + 2) * 64]);
         a1 = __builtin_bit_cast(half8, tab_lane[(2 * blk + 3) * 64]);
-        // the masks must be taken before acc0's registers are given to the next block's products
         // one test per block: does any lane have a negative among its 32 results?  (Measured: tests
         // per group of eight registers save instructions and lose as much to their branches.)
         const bool some = __ballot((int)(or16(acc0) | or16(acc1)) < 0) != 0;
         uint32_t m = 0;
         if (some) m = gather16(acc0) | (gather16(acc1) << 16);
+        // acc0's registers go to the next block's products only now that its signs are taken
         acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
+        if (!some) continue;
         sec.mark(9);
         // one (ray, sphere) pair per lane and turn, lowest register first
-        if (some)
         for (unsigned long long any = __ballot(m != 0); any != 0; any = __ballot(m != 0)) {
             if (m != 0) {
                 const int bit = __builtin_ctz(m);
                 m &= m - 1;
                 const int v = bit & 15;
-                const int s = 32 * blk + (v & 3) + 8 * (v >> 2) + row_of_half;
+                const int s = MF_BLOCK * (blk0 + blk) + (v & 3) + 8 * (v >> 2) + row_of_half;
                 const int owner = col | ((bit >> 4) << 5);
                 cq.ent[count + lane_rank(any)] = (unsigned)owner | ((unsigned)s << 6);
             }
@@ -208,6 +201,13 @@ __device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, 
         }
         sec.mark(8);
     }
+}
+
+// What is left in the queue, then the few spheres outside the table, then the winner.
+template <class F>
+__device__ __forceinline__ void mfma_scan_finish(const F &fr, const CandQ &cq, int &count, int lane, V3 o, V3 dh, bool live,
+                                                 float tmin, int self_id, const float4 *__restrict__ sph, float &best_t,
+                                                 int &best_id, SecClock &sec) {
     sec.mark(10);
     while (count > 0) resolve_batch(cq, count, min(count, 64), lane, o, dh, tmin, self_id, sph);
     sec.mark(11);
@@ -227,6 +227,66 @@ __device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, 
         best_t = __uint_as_float((unsigned)(key >> 32));
         best_id = (int)(unsigned)key;
     }
+}
+
+// Closest sphere hit of every lane's ray: the MFMA filter over the table resident in LDS, candidates
+// through the wave's queue (rt_device.h), the few spheres outside the table directly.  Whole wave; a
+// lane without a ray passes live = false.
+template <class F> // MfmaFrame, in whatever address space the launch parameters live
+__device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, V3 dh, bool live, float tmin,
+                                          int self_id, int lane, const CandQ &cq, const float4 *__restrict__ sph,
+                                          float &best_t, int &best_id, SecClock &sec) {
+    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
+    cq.slot[lane] = NO_HIT_KEY;
+    int count = 0; // queue fill, wave-uniform
+    sec.mark(8); // tuning build: 8 = matrix products and sign masks, 9 = recording, 10 = decisions, 11 = the rest
+    mfma_scan_blocks(tab + lane, 0, fr.n_blocks, op, cq, count, lane, o, dh, tmin, self_id, sph, sec);
+    mfma_scan_finish(fr, cq, count, lane, o, dh, live, tmin, self_id, sph, best_t, best_id, sec);
+}
+
+// The same with a table too large for LDS: it passes through two LDS buffers of MF_TILE_BLOCKS blocks,
+// the whole workgroup scanning in step (one barrier per tile; every wave of the workgroup must call this,
+// with or without rays).  A thread fetches its share of the next tile into registers before the wave
+// works on the current one and stores it afterwards, so the fetch costs no waiting.
+#ifndef RT_MF_TILE_BLOCKS
+#define RT_MF_TILE_BLOCKS 16
+#endif
+constexpr int MF_TILE_BLOCKS = RT_MF_TILE_BLOCKS;
+constexpr int MF_TILE_WORDS = (MF_TILE_BLOCKS + 1) * MF_BLOCK_WORDS; // with the block the read-ahead touches
+template <int WG_THREADS_T, class F>
+__device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *__restrict__ gtab, const F &fr, V3 o, V3 dh,
+                                                   bool live, float tmin, int self_id, int lane, const CandQ &cq,
+                                                   const float4 *__restrict__ sph, float &best_t, int &best_id,
+                                                   SecClock &sec) {
+    constexpr int PER_THREAD = MF_TILE_BLOCKS * MF_BLOCK_WORDS / WG_THREADS_T; // 16-byte words of a tile per thread
+    static_assert(PER_THREAD * WG_THREADS_T == MF_TILE_BLOCKS * MF_BLOCK_WORDS, "a tile divides evenly over the workgroup");
+    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
+    cq.slot[lane] = NO_HIT_KEY;
+    int count = 0;
+    const int n_tiles = fr.n_blocks / MF_TILE_BLOCKS; // the table is padded to whole tiles
+    const int tid = threadIdx.x;
+    uint4v next[PER_THREAD];
+    // the previous scan's readers of buffer 0 are done: every wave has passed the last barrier of that scan
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) bufs[tid + k * WG_THREADS_T] = gtab[tid + k * WG_THREADS_T];
+    __syncthreads();
+    sec.mark(8);
+    for (int t = 0; t < n_tiles; ++t) {
+        if (t + 1 < n_tiles) {
+            const uint4v *g = gtab + (size_t)(t + 1) * MF_TILE_BLOCKS * MF_BLOCK_WORDS;
+#pragma unroll
+            for (int k = 0; k < PER_THREAD; ++k) next[k] = g[tid + k * WG_THREADS_T];
+        }
+        mfma_scan_blocks(bufs + (t & 1) * MF_TILE_WORDS + lane, t * MF_TILE_BLOCKS, MF_TILE_BLOCKS, op, cq, count, lane, o, dh,
+                         tmin, self_id, sph, sec);
+        if (t + 1 < n_tiles) {
+            uint4v *dst = bufs + ((t + 1) & 1) * MF_TILE_WORDS;
+#pragma unroll
+            for (int k = 0; k < PER_THREAD; ++k) dst[tid + k * WG_THREADS_T] = next[k];
+        }
+        __syncthreads(); // the next tile is complete, and nobody still reads the buffer after it
+    }
+    mfma_scan_finish(fr, cq, count, lane, o, dh, live, tmin, self_id, sph, best_t, best_id, sec);
 }
 
 #endif // device code
