@@ -32,6 +32,8 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 256 FLOP/clk x 2.4
 FLOP_PER_TEST = 17        # one ray/sphere test as the reference states it: oc 3, oc.d 5, oc.oc - r^2 6, hb^2 - a*c 3
 FLOP_PER_TEST_EXECUTED = 14  # what the kernel issues per test: 7 fused multiply-adds of the packed filter
 FLOP_PER_RAY = 80         # per closest-hit query: d.d, hit point, normal, scatter / sky
+PEAK_MFMA_F16_TFLOPS = 2516.6  # MI355X dense f16 matrix peak: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
+FLOP_PER_ROW_MFMA = 64    # the matrix-core filter: K = 32 multiply-adds per (ray, table row)
 
 WORKLOADS = {
     "c2": dict(scene="small", width=1920, height=1080, spp=100, depth=50),
@@ -146,6 +148,29 @@ class Job:
         achieved = rays_per_launch * (FLOP_PER_TEST * n_s + FLOP_PER_RAY) / (kern_ms * 1e-3) / 1e12
         executed = rays_per_launch * (FLOP_PER_TEST_EXECUTED * n_s + FLOP_PER_RAY) / (kern_ms * 1e-3) / 1e12
         traffic, traffic_src = committed_traffic(self.name, args, self.world)
+        info = self.r.filter_describe()
+        if info["in_use"]:
+            # The sphere filter runs on the matrix cores (split-f16 bilinear form): the roofline of the
+            # arithmetic is the dense f16 MFMA peak, priced at the products the kernel really issues for the
+            # rays it traced.  The algorithmic rate of the reference's fp32 formulation is given beside it, with
+            # the FP32 vector peak that bounded the packed-FP32 form of the same filter.
+            mfma = rays_per_launch * FLOP_PER_ROW_MFMA * info["n_rows"] / (kern_ms * 1e-3) / 1e12
+            return {
+                "bound": "mfma",
+                "achieved": round(mfma, 3),
+                "peak": PEAK_MFMA_F16_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(mfma / PEAK_MFMA_F16_TFLOPS, 4),
+                "algorithmic_tflops": round(achieved, 3),
+                "fp32_valu_peak": PEAK_FP32_TFLOPS,
+                "algorithmic_over_fp32_valu_peak": round(achieved / PEAK_FP32_TFLOPS, 4),
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "kernel": "render_kernel",
+                "kernel_ms": round(kern_ms, 3),
+                "flop_model": f"matrix: rays*{FLOP_PER_ROW_MFMA}*{info['n_rows']} table rows; algorithmic: "
+                              f"rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}); rays/launch={rays_per_launch:.0f}",
+            }
         return {
             "bound": "valu_fp32",
             "achieved": round(achieved, 3),
