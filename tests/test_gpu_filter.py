@@ -131,3 +131,96 @@ def test_frames_are_the_same_bytes_with_either_filter(monkeypatch):
         b = r.render_host(p, want_accum=True)
     assert a[2] == b[2]
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ---- scenes built to strain the filter's frame: where its centre, its scale and its table layout come from ----
+
+def _cloud(name, n, seed, centre=(0.0, 0.0, 0.0), box=(10.0, 10.0, 3.0), radii=(0.05, 0.6), extra=()):
+    """n spheres of mixed materials scattered in a box around `centre`, then `extra` (centre, radius) spheres."""
+    rng = np.random.default_rng(seed)
+    b = scenes._Builder()
+    mats = [b.lambertian((0.6, 0.5, 0.4)), b.metal((0.8, 0.8, 0.7), 0.1), b.dielectric((1.0, 1.0, 1.0), 1.5),
+            b.lambertian((0.2, 0.5, 0.7))]
+    c0 = np.asarray(centre, dtype=np.float64)
+    for i in range(n):
+        c = c0 + (rng.random(3) - 0.5) * 2.0 * np.asarray(box)
+        r = radii[0] * (radii[1] / radii[0]) ** rng.random()  # log-uniform
+        b.sphere(c, r, mats[i % len(mats)])
+    for c, r in extra:
+        b.sphere(np.asarray(c, dtype=np.float64) + c0, r, mats[0])
+    eye = c0 + np.array([1.6 * box[0], -1.3 * box[1], 2.5 * box[2] + 2.0])
+    return b.build(name, scenes.make_camera(eye, c0 - eye))
+
+
+def _strain_scenes():
+    return {
+        # the frame's centre is rounded to float, and ray origins sit far from the world origin
+        "offset": _cloud("offset", 300, 1, centre=(5000.0, -3000.0, 2000.0)),
+        # three decades of radii, some of them negative (the reference's hitDetail only ever squares the radius)
+        "radii": _cloud("radii", 200, 2, radii=(0.003, 3.0),
+                        extra=[((1.0, 2.0, 0.5), -0.7), ((-3.0, 1.0, 0.0), -0.05)]),
+        # more very large spheres than the filter decides outside its table: the frame has to span them
+        "many_big": _cloud("many_big", 120, 3, extra=[((40.0 * np.cos(k), 40.0 * np.sin(k), -300.0 - 20.0 * k), 300.0 + 10.0 * k)
+                                                       for k in range(12)]),
+        # nested shells around one point and a row of spheres on a line: degenerate clouds
+        "shells": _cloud("shells", 0, 4, extra=[((0.0, 0.0, 0.0), 0.1 * (k + 1)) for k in range(20)]),
+        "row": _cloud("row", 0, 5, extra=[((0.9 * k - 18.0, 0.0, 0.0), 0.4) for k in range(40)]),
+        # the smallest table (one more sphere than the direct decision takes) and one streamed through LDS in tiles
+        "nine": _cloud("nine", 9, 6),
+        "streamed": _cloud("streamed", 2600, 7, box=(30.0, 30.0, 4.0), radii=(0.1, 0.5)),
+    }
+
+
+@pytest.mark.parametrize("name", ["offset", "radii", "many_big", "shells", "row", "nine", "streamed"])
+def test_strained_frames_drop_no_hit(name):
+    """The superset property on scenes that stress how the filter's frame is chosen, with origins up to 10^4
+    cloud radii away; and a frame rendered with either filter has the same bytes and ray count."""
+    scene = _strain_scenes()[name]
+    rng = np.random.default_rng(11)
+    p = RenderParams(96, 64, 16, 12, seed=5)
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        info = r.filter_describe()
+        assert info["in_use"] and info["n_rows"] >= len(scene.spheres) - len(info["big"])
+        org, d = _rays(scene, 4096, rng, spread=info["radius"])
+        # a few origins very far out, aimed back at the cloud
+        far = rng.random(len(org)) < 0.05
+        org[far] = (info["center"] + (org[far] - info["center"]) * 1.0e4 / 60.0).astype(np.float32)
+        d[far] = (info["center"] + rng.normal(size=(far.sum(), 3)) * 0.3 * info["radius"] - org[far]).astype(np.float32)
+        vals = r.filter_values(org, d).astype(np.float64)
+        a = r.render_host(p, want_accum=True)
+    F, m_ray, pnorm = _exact(scene, info, org, d)
+    n = len(scene.spheres)
+    table = np.ones(n, dtype=bool)
+    table[info["big"]] = False
+    v = vals[:, :n][:, table]
+    Ft = F[:, table]
+    # a double evaluation from the same float inputs; what the exact decision can still accept lies within
+    # rounding of zero, scaled by the size of the terms that cancel (|O'|^2 for far origins)
+    oprime = np.abs((org.astype(np.float64) - info["center"][None, :]) / info["radius"]).max(axis=1)
+    slack = 1e-6 * (np.abs(_xyzr(scene)[table, 3]) / info["radius"])[None, :] ** 2
+    meets = Ft >= -slack
+    dropped = meets & ~(v < 0)
+    assert not dropped.any(), f"{dropped.sum()} hits dropped, e.g. ray {np.argwhere(dropped)[0]}, |O'| {oprime[np.argwhere(dropped)[0][0]]:.3g}"
+    assert (vals[:, ~np.pad(table, (0, vals.shape[1] - n))] > 0).all()
+    near = (pnorm <= 1.0) & (oprime <= 100.0)
+    err = (np.abs(v + (Ft + m_ray[:, None])) / m_ray[:, None])[near]
+    print(f"{name}: {n} spheres, {len(info['big'])} outside the table, {meets.sum()} meetings, largest error "
+          f"{err.max():.3f} of the margin, passing {100.0 * (v < 0).mean():.3f} % vs meeting {100.0 * (Ft >= 0).mean():.3f} %")
+    assert err.max() <= 0.75
+
+    import os
+    old = os.environ.get("RT_AMD_SPHERE_SOURCE")
+    os.environ["RT_AMD_SPHERE_SOURCE"] = "scalar"
+    try:
+        with Renderer(0) as r:
+            r.set_scene(scene)
+            assert not r.filter_describe()["in_use"]
+            b = r.render_host(p, want_accum=True)
+    finally:
+        if old is None:
+            del os.environ["RT_AMD_SPHERE_SOURCE"]
+        else:
+            os.environ["RT_AMD_SPHERE_SOURCE"] = old
+    assert a[2] == b[2], f"ray counts differ: {a[2]} vs {b[2]}"
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
