@@ -427,7 +427,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? 1 : 
         int best_id = -1;
         const float tmin = TMIN * pt.len;
         RayK rk = make_rayk(pt.o, pt.dh);
-        if (SRC == SRC_LDS_STREAMED) {
+        if constexpr (SRC == SRC_LDS_STREAMED) {
             for (int base = 0; base < nquads; base += STREAM_QUADS) {
                 int cnt = min(STREAM_QUADS, nquads - base);
                 __syncthreads();
@@ -437,11 +437,11 @@ __global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? 1 : 
                 if (active)
                     scan_lds(lds_sph, lds_r2, cnt, 4 * base, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
             }
-        } else if (SRC == SRC_LDS_RESIDENT) {
+        } else if constexpr (SRC == SRC_LDS_RESIDENT) {
             if (active) scan_lds(lds_sph, lds_r2, nquads, 0, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
-        } else if (SRC == SRC_MFMA) {
+        } else if constexpr (SRC == SRC_MFMA) {
             scan_mfma(lds_tab, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph, best_t, best_id, sec);
-        } else if (SRC == SRC_MFMA_STREAMED) {
+        } else if constexpr (SRC == SRC_MFMA_STREAMED) {
             scan_mfma_streamed<WGT>(lds_tab, KS.mf_table, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph,
                                     best_t, best_id, sec);
         } else {
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(64) void filter_probe_kernel(int n_rays, const floa
         const float16v acc1 = mfma_tile(a0, a1, op.b[1][0], op.b[1][1]);
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int row = MF_BLOCK * blk + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+            const int row = MF_BLOCK * blk + v + 16 * (lane >> 5); // the sphere behind register v (rt_mfma.h)
             const int r0 = base + (lane & 31), r1 = r0 + 32;
             if (r0 < n_rays) out[(size_t)r0 * n_rows + row] = acc0[v] * (1.0f / (MF_SCALE * MF_SCALE));
             if (r1 < n_rays) out[(size_t)r1 * n_rows + row] = acc1[v] * (1.0f / (MF_SCALE * MF_SCALE));
@@ -1636,7 +1636,7 @@ MfTable build_mf_table(const std::vector<float4> &sph) {
         w[13] = pack(lo[8], q_hi);
         w[14] = pack(q_lo, 0);
         w[15] = pack(unit, unit);
-        const int blk = row / MF_BLOCK, r = row % MF_BLOCK;
+        const int blk = row / MF_BLOCK, r = mf_row_of_sphere(row % MF_BLOCK);
         for (int step = 0; step < 2; ++step)
             for (int h = 0; h < 2; ++h)
                 for (int i = 0; i < 4; ++i)

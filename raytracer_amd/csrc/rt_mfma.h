@@ -57,6 +57,9 @@ struct MfmaFrame {
     int big[MF_MAX_BIG]; // indices of the spheres decided directly
 };
 
+// Matrix row (0..31) of a table block that holds the block's i-th sphere.
+constexpr int mf_row_of_sphere(int i) { return (i & 3) + 8 * ((i & 15) >> 2) + 4 * (i >> 4); }
+
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 
 __device__ __forceinline__ uint32_t pack_rtz(float a, float b) {
@@ -127,14 +130,16 @@ __device__ __forceinline__ RayOperand mfma_ray_operand(V3 o, V3 dh, bool live, f
     return op;
 }
 
-// One 32x32 result tile: register v of lane l is sphere (v & 3) + 8 (v >> 2) + 4 (l >> 5) of the table
-// block behind (a0, a1) against the ray of lane l & 31 of the ray half behind (b0, b1).
+// One 32x32 result tile: register v of lane l is matrix row (v & 3) + 8 (v >> 2) + 4 (l >> 5) of the table
+// block behind (a0, a1) against the ray of lane l & 31 of the ray half behind (b0, b1).  The host lays the
+// block's spheres out so that this row holds sphere v + 16 (l >> 5) of the block (mf_row_of_sphere): a
+// result's sphere index is then linear in its register number.
 __device__ __forceinline__ float16v mfma_tile(half8 a0, half8 a1, half8 b0, half8 b1) {
     const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, zero, 0, 0, 0), 0, 0, 0);
 }
 
-// Sign bits of a result tile, register v in bit v.  On this chip every vector instruction holds the
+// Sign bits of result tiles.  On this chip every vector instruction holds the
 // issue port for about four cycles, so what counts is their number: gathering the signs takes one
 // v_alignbit_b32 per register, OR-ing the registers half as many instructions (v_or3_b32), and a ray
 // passes the filter for about one sphere in three hundred: more than half of the blocks pass for no
@@ -145,14 +150,17 @@ __device__ __forceinline__ uint32_t or16(const float16v &acc) {
     for (int v = 0; v < 16; ++v) any |= __float_as_uint(acc[v]);
     return any;
 }
-__device__ __forceinline__ uint32_t gather16(const float16v &acc) {
+// Sign bits of the two result tiles of a block: bit 2 v + h = register v of ray half h.
+__device__ __forceinline__ uint32_t gather32(const float16v &acc0, const float16v &acc1) {
     uint32_t lo = 0, hi = 0; // two chains: dependent instructions are not back to back
 #pragma unroll
     for (int v = 7; v >= 0; --v) {
-        lo = __builtin_amdgcn_alignbit(lo, __float_as_uint(acc[v]), 31);
-        hi = __builtin_amdgcn_alignbit(hi, __float_as_uint(acc[8 + v]), 31);
+        lo = __builtin_amdgcn_alignbit(lo, __float_as_uint(acc1[v]), 31);
+        hi = __builtin_amdgcn_alignbit(hi, __float_as_uint(acc1[8 + v]), 31);
+        lo = __builtin_amdgcn_alignbit(lo, __float_as_uint(acc0[v]), 31);
+        hi = __builtin_amdgcn_alignbit(hi, __float_as_uint(acc0[8 + v]), 31);
     }
-    return lo | (hi << 8);
+    return lo | (hi << 16);
 }
 
 // Filter of `nblk` table blocks at `tab_lane` (LDS, this lane's words; block b of the run is table block
@@ -163,8 +171,9 @@ __device__ __forceinline__ uint32_t gather16(const float16v &acc) {
 __device__ __forceinline__ void mfma_scan_blocks(const uint4v *tab_lane, int blk0, int nblk, const RayOperand &op,
                                                  const CandQ &cq, int &count, int lane, V3 o, V3 dh, float tmin,
                                                  int self_id, const float4 *__restrict__ sph, SecClock &sec) {
-    const int row_of_half = 4 * (lane >> 5);
-    const int col = lane & 31;
+    // queue entry of the result in register v of ray half h: owner lane | sphere << 6, which is this plus
+    // (2 v + h) << 5 plus the block number << 11
+    const unsigned lane_part = (unsigned)(lane & 31) | ((unsigned)(lane >> 5) << 10);
     half8 a0 = __builtin_bit_cast(half8, tab_lane[0]), a1 = __builtin_bit_cast(half8, tab_lane[64]);
     float16v acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
 #pragma unroll 1
@@ -174,22 +183,24 @@ __device__ __forceinline__ void mfma_scan_blocks(const uint4v *tab_lane, int blk
         a1 = __builtin_bit_cast(half8, tab_lane[(2 * blk + 3) * 64]);
         // one test per block: does any lane have a negative among its 32 results?  (Measured: tests
         // per group of eight registers save instructions and lose as much to their branches.)
+#ifdef RT_MF_PROBE_NO_CANDIDATES // timing probe: the products and their examination alone (frames are wrong)
+        const bool some = __ballot((int)(or16(acc0) | or16(acc1)) == 0x7fffffff) != 0;
+#else
         const bool some = __ballot((int)(or16(acc0) | or16(acc1)) < 0) != 0;
+#endif
         uint32_t m = 0;
-        if (some) m = gather16(acc0) | (gather16(acc1) << 16);
+        if (some) m = gather32(acc0, acc1);
         // acc0's registers go to the next block's products only now that its signs are taken
         acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
         if (!some) continue;
         sec.mark(9);
+        const unsigned block_part = lane_part | ((unsigned)(blk0 + blk) << 11);
         // one (ray, sphere) pair per lane and turn, lowest register first
         for (unsigned long long any = __ballot(m != 0); any != 0; any = __ballot(m != 0)) {
             if (m != 0) {
-                const int bit = __builtin_ctz(m);
+                const unsigned bit = (unsigned)__builtin_ctz(m);
                 m &= m - 1;
-                const int v = bit & 15;
-                const int s = MF_BLOCK * (blk0 + blk) + (v & 3) + 8 * (v >> 2) + row_of_half;
-                const int owner = col | ((bit >> 4) << 5);
-                cq.ent[count + lane_rank(any)] = (unsigned)owner | ((unsigned)s << 6);
+                cq.ent[count + lane_rank(any)] = block_part + (bit << 5);
             }
             count += (int)__popcll(any);
             if (count >= 64) {

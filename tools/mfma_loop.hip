@@ -1,0 +1,120 @@
+// Micro-benchmark (gfx950): the block loop of the matrix-core sphere filter on its own -- table words from
+// LDS one block ahead, two dependent v_mfma_f32_32x32x16_f16 per ray half, 16 v_or3_b32 over the 32 results,
+// one ballot -- in variants that leave parts out, to see which part sets the pace.  16 waves per workgroup,
+// one workgroup per CU, as the render kernel runs it.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/mfma_loop.bin tools/mfma_loop.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+#include <algorithm>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+
+enum { V_FULL, V_NO_LDS, V_NO_OR, V_MFMA_ONLY, V_OR_ONLY, V_FULL_INDEP, V_FULL_3ACC, V_MODES };
+static const char *names[V_MODES] = {"full loop", "no LDS reads", "no or / ballot", "MFMA only", "or + LDS, no MFMA",
+                                     "full, k-steps into separate accumulators", "full, 16x16x32 shape"};
+
+__device__ __forceinline__ float16v tile(half8 a0, half8 a1, half8 b0, half8 b1) {
+    const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, zero, 0, 0, 0), 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t or16(const float16v &acc) {
+    uint32_t any = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) any |= __float_as_uint(acc[v]);
+    return any;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024, 4) void k(const uint4v *__restrict__ gtab, int n_blocks, int reps, float *out,
+                                             unsigned long long *cyc, float s) {
+    extern __shared__ __attribute__((aligned(16))) uint4v tab[];
+    for (int i = threadIdx.x; i < (n_blocks + 1) * 128; i += 1024) tab[i] = gtab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint4v *tl = tab + lane;
+    half8 b00, b01, b10, b11;
+    for (int j = 0; j < 8; ++j) {
+        b00[j] = (_Float16)(s * (1 + j + lane));
+        b01[j] = (_Float16)(s * (2 + j));
+        b10[j] = (_Float16)(s * (3 + j + lane));
+        b11[j] = (_Float16)(s * (4 + j));
+    }
+    unsigned found = 0;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < reps; ++r) {
+        half8 a0 = __builtin_bit_cast(half8, tl[0]), a1 = __builtin_bit_cast(half8, tl[64]);
+        float16v acc0 = tile(a0, a1, b00, b01);
+#pragma unroll 1
+        for (int blk = 0; blk < n_blocks; ++blk) {
+            float16v acc1;
+            if (MODE == V_OR_ONLY) {
+                acc1 = acc0;
+                acc1[0] += 1.0f;
+            } else {
+                acc1 = tile(a0, a1, b10, b11);
+            }
+            if (MODE != V_NO_LDS && MODE != V_MFMA_ONLY) {
+                a0 = __builtin_bit_cast(half8, tl[(2 * blk + 2) * 64]);
+                a1 = __builtin_bit_cast(half8, tl[(2 * blk + 3) * 64]);
+            }
+            if (MODE != V_NO_OR && MODE != V_MFMA_ONLY) {
+                const bool some = __ballot((int)(or16(acc0) | or16(acc1)) < 0) != 0;
+                if (some) found++;
+            } else {
+                asm volatile("" ::"v"(acc0), "v"(acc1));
+            }
+            if (MODE == V_OR_ONLY) {
+                acc0[1] += 1.0f;
+            } else {
+                acc0 = tile(a0, a1, b00, b01);
+            }
+        }
+        asm volatile("" ::"v"(acc0));
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)found;
+    if (lane == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+
+template <int MODE>
+void run(const uint4v *dtab, int n_blocks, int reps, float *d, unsigned long long *dc, std::vector<unsigned long long> &h) {
+    const size_t lds = (size_t)(n_blocks + 1) * 2048;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(1024), lds, 0, dtab, n_blocks, 2, d, dc, 1.0f);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(1024), lds, 0, dtab, n_blocks, reps, d, dc, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const size_t nw = 256 * 16;
+    hipMemcpy(h.data(), dc, nw * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.begin() + nw);
+    const double blocks = (double)reps * n_blocks;
+    // wall time per block per SIMD (4 waves share a SIMD) at the shader clock the event time implies
+    printf("  %-44s %8.3f ms  = %6.1f ns per block per wave; s_memtime median %7.1f ticks per block per wave\n", names[MODE], ms,
+           ms * 1e6 / blocks, (double)h[nw / 2] / blocks);
+}
+
+int main() {
+    const int n_blocks = 16, reps = 20000;
+    std::vector<uint32_t> tabh((size_t)(n_blocks + 1) * 128 * 4);
+    // half-float words near 1.0 so that every product is positive: no sign bit, no candidate
+    for (auto &w : tabh) w = 0x3c003c00u;
+    uint4v *dtab; hipMalloc(&dtab, tabh.size() * 4);
+    hipMemcpy(dtab, tabh.data(), tabh.size() * 4, hipMemcpyHostToDevice);
+    float *d; hipMalloc(&d, 256 * 1024 * 4);
+    unsigned long long *dc; hipMalloc(&dc, 256 * 16 * 8);
+    std::vector<unsigned long long> h(256 * 16);
+    printf("16 waves per CU (4 per SIMD), %d blocks of 32 rows x 64 rays, %d scans per wave\n", n_blocks, reps);
+    run<V_FULL>(dtab, n_blocks, reps, d, dc, h);
+    run<V_NO_LDS>(dtab, n_blocks, reps, d, dc, h);
+    run<V_NO_OR>(dtab, n_blocks, reps, d, dc, h);
+    run<V_MFMA_ONLY>(dtab, n_blocks, reps, d, dc, h);
+    run<V_OR_ONLY>(dtab, n_blocks, reps, d, dc, h);
+    return 0;
+}
