@@ -193,11 +193,14 @@ __device__ __forceinline__ void mfma_scan_blocks(const uint4v *tab_lane, int blk
         // acc0's registers go to the next block's products only now that its signs are taken
         acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
         if (!some) continue;
+        RT_STAT(2); // tuning build: blocks whose sign bits were gathered (per wave)
         sec.mark(9);
         const unsigned block_part = lane_part | ((unsigned)(blk0 + blk) << 11);
         // one (ray, sphere) pair per lane and turn, lowest register first
         for (unsigned long long any = __ballot(m != 0); any != 0; any = __ballot(m != 0)) {
+            RT_STAT(3); // turns of the recording loop (per wave)
             if (m != 0) {
+                RT_STAT_LANES(5); // pairs recorded
                 const unsigned bit = (unsigned)__builtin_ctz(m);
                 m &= m - 1;
                 cq.ent[count + lane_rank(any)] = block_part + (bit << 5);

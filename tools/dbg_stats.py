@@ -20,6 +20,9 @@ _, _, rays = r.render_host(RenderParams(W, H, spp, depth))
 lib.rt_debug_stats(out, 0)
 q_w, q_l, b_w, b_l, s_w, s_l, upd, g8 = list(out)[:8]
 print(f"{name}: rays {rays}, scan iterations (per wave) {q_w}, lanes with a ray {q_l/max(q_w,1):.2f} of 64")
+if r.filter_describe()["in_use"]:
+    print(f"  matrix-core filter: blocks gathered {b_w/max(q_w,1):.2f} per scan, recording turns {b_l/max(q_w,1):.2f} per scan "
+          f"({b_l/max(b_w,1):.2f} per gathered block), pairs recorded {s_l/max(q_w,1):.1f} per scan = {s_l/max(rays,1):.2f} per ray")
 print(f"  groups of eight entered: per wave {g8} = {g8/max(q_w,1):.2f} per scan")
 print(f"  quad bodies: per wave {b_w} = {b_w/max(q_w,1):.2f} per scan; lanes inside {b_l/max(b_w,1):.2f}")
 print(f"  sphere bodies: per wave {s_w} = {s_w/max(b_w,1):.2f} per quad body; lanes inside {s_l/max(s_w,1):.2f}")

@@ -11,9 +11,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
 
-enum { V_FULL, V_NO_LDS, V_NO_OR, V_MFMA_ONLY, V_OR_ONLY, V_FULL_INDEP, V_FULL_3ACC, V_MODES };
+enum { V_FULL, V_NO_LDS, V_NO_OR, V_MFMA_ONLY, V_OR_ONLY, V_TILES, V_TILES_BARRIER, V_TILES_STREAM, V_MODES };
 static const char *names[V_MODES] = {"full loop", "no LDS reads", "no or / ballot", "MFMA only", "or + LDS, no MFMA",
-                                     "full, k-steps into separate accumulators", "full, 16x16x32 shape"};
+                                     "full, restarted every 16 blocks", "  + a barrier every 16 blocks", "  + the next 16 blocks staged through registers"};
 
 __device__ __forceinline__ float16v tile(half8 a0, half8 a1, half8 b0, half8 b1) {
     const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -100,11 +100,84 @@ void run(const uint4v *dtab, int n_blocks, int reps, float *d, unsigned long lon
            ms * 1e6 / blocks, (double)h[nw / 2] / blocks);
 }
 
-int main() {
+// The streamed form: the loop restarts every 16 blocks (pipeline prologue and one wasted read-ahead tile), with a
+// workgroup barrier per tile, and with the next tile fetched from global memory into registers before the blocks
+// and stored to the other LDS buffer after them.
+template <int MODE>
+__global__ __launch_bounds__(1024, 4) void kt(const uint4v *__restrict__ gtab, int n_tiles, int reps, float *out,
+                                              unsigned long long *cyc, float s) {
+    extern __shared__ __attribute__((aligned(16))) uint4v tab[];
+    constexpr int TB = 16, TW = (TB + 1) * 128;
+    for (int i = threadIdx.x; i < 2 * TW; i += 1024) tab[i] = gtab[i % (TB * 128)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, tid = threadIdx.x;
+    half8 b00, b01, b10, b11;
+    for (int j = 0; j < 8; ++j) {
+        b00[j] = (_Float16)(s * (1 + j + lane));
+        b01[j] = (_Float16)(s * (2 + j));
+        b10[j] = (_Float16)(s * (3 + j + lane));
+        b11[j] = (_Float16)(s * (4 + j));
+    }
+    unsigned found = 0;
+    for (int r = 0; r < reps; ++r) {
+        for (int t = 0; t < n_tiles; ++t) {
+            uint4v next[2];
+            if (MODE == V_TILES_STREAM) {
+                const uint4v *g = gtab + (size_t)((t + 1) % n_tiles) * TB * 128;
+                next[0] = g[tid];
+                next[1] = g[tid + 1024];
+            }
+            const uint4v *tl = tab + (t & 1) * TW + lane;
+            half8 a0 = __builtin_bit_cast(half8, tl[0]), a1 = __builtin_bit_cast(half8, tl[64]);
+            float16v acc0 = tile(a0, a1, b00, b01);
+#pragma unroll 1
+            for (int blk = 0; blk < TB; ++blk) {
+                float16v acc1 = tile(a0, a1, b10, b11);
+                a0 = __builtin_bit_cast(half8, tl[(2 * blk + 2) * 64]);
+                a1 = __builtin_bit_cast(half8, tl[(2 * blk + 3) * 64]);
+                const bool some = __ballot((int)(or16(acc0) | or16(acc1)) < 0) != 0;
+                if (some) found++;
+                acc0 = tile(a0, a1, b00, b01);
+            }
+            asm volatile("" ::"v"(acc0));
+            if (MODE == V_TILES_STREAM) {
+                uint4v *dst = tab + ((t + 1) & 1) * TW;
+                dst[tid] = next[0];
+                dst[tid + 1024] = next[1];
+            }
+            if (MODE != V_TILES) __syncthreads();
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)found;
+    (void)cyc;
+}
+
+template <int MODE>
+void run_tiled(const uint4v *dtab, int n_tiles, int reps, float *d, unsigned long long *dc) {
+    const size_t lds = 2 * 17 * 2048;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&kt<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kt<MODE>, dim3(256), dim3(1024), lds, 0, dtab, n_tiles, 2, d, dc, 1.0f);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kt<MODE>, dim3(256), dim3(1024), lds, 0, dtab, n_tiles, reps, d, dc, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double blocks = (double)reps * n_tiles * 16;
+    printf("  %-44s %8.3f ms  = %6.1f ns per block per wave\n", names[MODE], ms, ms * 1e6 / blocks);
+}
+
+int main(int argc, char **argv) {
+    const bool random_data = argc > 1;
     const int n_blocks = 16, reps = 20000;
     std::vector<uint32_t> tabh((size_t)(n_blocks + 1) * 128 * 4);
     // half-float words near 1.0 so that every product is positive: no sign bit, no candidate
-    for (auto &w : tabh) w = 0x3c003c00u;
+    // (argument "random": random magnitudes below 1, still all positive, to see what the data costs in power)
+    unsigned seed = 12345u;
+    auto rnd_pos = [&]() { seed = seed * 1664525u + 1013904223u; return (uint32_t)(0x3000u + ((seed >> 12) & 0x0bffu)); };
+    for (auto &w : tabh) w = random_data ? (rnd_pos() | (rnd_pos() << 16)) : 0x3c003c00u;
     uint4v *dtab; hipMalloc(&dtab, tabh.size() * 4);
     hipMemcpy(dtab, tabh.data(), tabh.size() * 4, hipMemcpyHostToDevice);
     float *d; hipMalloc(&d, 256 * 1024 * 4);
@@ -116,5 +189,16 @@ int main() {
     run<V_NO_OR>(dtab, n_blocks, reps, d, dc, h);
     run<V_MFMA_ONLY>(dtab, n_blocks, reps, d, dc, h);
     run<V_OR_ONLY>(dtab, n_blocks, reps, d, dc, h);
+    {
+        // a table of 20 tiles (the 10 001-sphere scene), streamed
+        const int n_tiles = 20;
+        std::vector<uint32_t> big((size_t)n_tiles * 16 * 128 * 4, 0x3c003c00u);
+        if (random_data) for (auto &w : big) w = rnd_pos() | (rnd_pos() << 16);
+        uint4v *dbig; hipMalloc(&dbig, big.size() * 4);
+        hipMemcpy(dbig, big.data(), big.size() * 4, hipMemcpyHostToDevice);
+        run_tiled<V_TILES>(dbig, n_tiles, random_data ? 20000 : 1000, d, dc);
+        run_tiled<V_TILES_BARRIER>(dbig, n_tiles, 1000, d, dc);
+        run_tiled<V_TILES_STREAM>(dbig, n_tiles, 1000, d, dc);
+    }
     return 0;
 }
