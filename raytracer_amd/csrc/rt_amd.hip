@@ -1214,6 +1214,7 @@ struct rt_ctx {
     MfmaFrame mf{};
     bool mf_usable = false;  // the scene has a table and it fits in LDS
     bool mf_wanted = true;   // RT_AMD_SPHERE_SOURCE did not ask for another source
+    int mf_resident = 0;     // workgroups of the scene's matrix-core variant a CU holds (queried at upload)
     unsigned char *d_queue = nullptr; // ring of work-item counters of the persistent render kernel
     unsigned queue_next = 0;          // next slot of the ring
     unsigned char *d_scratch = nullptr; // this device's copy of `scratch` (rt_render_noalloc)
@@ -1748,7 +1749,20 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
         HIP_TRY(ctx, reserve(ctx, (void **)&ctx->d_mf_table, mft.words.size() * 4));
         HIP_TRY(ctx, hipMemcpy(ctx->d_mf_table, mft.words.data(), mft.words.size() * 4, hipMemcpyHostToDevice));
         ctx->mf = mft.fr;
-        ctx->mf_usable = true;
+        // how many workgroups of the variant this table takes stay resident on a CU: asked once per scene, so a
+        // render issues nothing but its counter reset and its launch
+        const bool fits = mf_lds_resident(mft.fr.n_blocks) <= MF_LDS_BYTES;
+        int resident = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &resident,
+                fits ? reinterpret_cast<const void *>(&render_kernel<SRC_MFMA, false>)
+                     : reinterpret_cast<const void *>(&render_kernel<SRC_MFMA_STREAMED, false>),
+                wg_threads_of(fits ? SRC_MFMA : SRC_MFMA_STREAMED),
+                fits ? mf_lds_resident(mft.fr.n_blocks) : MF_LDS_STREAMED) != hipSuccess)
+            resident = 0;
+        (void)hipGetLastError();
+        ctx->mf_resident = resident;
+        ctx->mf_usable = resident >= 1; // a device that cannot hold the workgroup scans with the packed filter
     }
     if ((rc = to_device(ctx, &ctx->d_mat_id, mid)) != RT_OK) return rc;
     if ((rc = to_device(ctx, &ctx->d_mats, mats)) != RT_OK) return rc;
@@ -1906,13 +1920,7 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
         src = fits ? SRC_MFMA : SRC_MFMA_STREAMED;
         k.mf = ctx->mf;
         lds = fits ? mf_lds_resident(ctx->mf.n_blocks) : MF_LDS_STREAMED;
-        int resident = 0;
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                         &resident,
-                         fits ? reinterpret_cast<const void *>(&render_kernel<SRC_MFMA, false>)
-                              : reinterpret_cast<const void *>(&render_kernel<SRC_MFMA_STREAMED, false>),
-                         wg_threads_of(src), lds));
-        if (resident < 1) return fail(ctx, RT_ERR_HIP, "the matrix-core render kernel does not fit on a CU");
+        const int resident = ctx->mf_resident;
         const int wpw = wg_threads_of(src) / 64;
         want = (items + wpw - 1) / wpw;
         cap = (long long)ctx->n_cus * resident;
