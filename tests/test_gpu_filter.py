@@ -168,10 +168,14 @@ def _strain_scenes():
         # the smallest table (one more sphere than the direct decision takes) and one streamed through LDS in tiles
         "nine": _cloud("nine", 9, 6),
         "streamed": _cloud("streamed", 2600, 7, box=(30.0, 30.0, 4.0), radii=(0.1, 0.5)),
+        # the largest table that stays resident in LDS (46 blocks of 32) and the first that does not
+        "edge_resident": _cloud("edge_resident", 1472, 8, box=(25.0, 25.0, 4.0), radii=(0.1, 0.5)),
+        "edge_streamed": _cloud("edge_streamed", 1473, 8, box=(25.0, 25.0, 4.0), radii=(0.1, 0.5)),
     }
 
 
-@pytest.mark.parametrize("name", ["offset", "radii", "many_big", "shells", "row", "nine", "streamed"])
+@pytest.mark.parametrize("name", ["offset", "radii", "many_big", "shells", "row", "nine", "streamed", "edge_resident",
+                                  "edge_streamed"])
 def test_strained_frames_drop_no_hit(name):
     """The superset property on scenes that stress how the filter's frame is chosen, with origins up to 10^4
     cloud radii away; and a frame rendered with either filter has the same bytes and ray count."""
@@ -182,6 +186,8 @@ def test_strained_frames_drop_no_hit(name):
         r.set_scene(scene)
         info = r.filter_describe()
         assert info["in_use"] and info["n_rows"] >= len(scene.spheres) - len(info["big"])
+        if name.startswith("edge"):
+            assert not info["big"] and info["n_rows"] == (1472 if name == "edge_resident" else 1536)  # whole tiles of 16 blocks
         org, d = _rays(scene, 4096, rng, spread=info["radius"])
         # a few origins very far out, aimed back at the cloud
         far = rng.random(len(org)) < 0.05
