@@ -1124,6 +1124,52 @@ __global__ __launch_bounds__(WG_THREADS) void first_hit_kernel(int n_rays, const
     }
 }
 
+// First hits of a sphere-only scene through the scan the render kernel runs on it: matrix-core filter over the
+// scene's table (read from global memory here), candidate queue, exact decisions (rt_mfma.h).  One ray per
+// lane; every wave runs whole, lanes past the last ray included.
+__global__ __launch_bounds__(WG_THREADS) void first_hit_mfma_kernel(int n_rays, const float *__restrict__ org,
+                                                                    const float *__restrict__ dir, float tmin,
+                                                                    DeviceScene sc, MfmaFrame fr, int32_t *__restrict__ id,
+                                                                    float *__restrict__ t, float *__restrict__ normal,
+                                                                    uint8_t *__restrict__ front,
+                                                                    uint8_t *__restrict__ expanded) {
+    __shared__ unsigned long long slots[WAVES_PER_WG * 64];
+    __shared__ unsigned ents[WAVES_PER_WG * cand_cap_of(SRC_MFMA)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * WG_THREADS + threadIdx.x;
+    const bool live = i < n_rays;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    if (live) {
+        o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+        d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    }
+    const float a = dot(d, d);
+    const float inv_len = __frsqrt_rn(a), len = a * inv_len; // as set_dir() does
+    const V3 dh = d * inv_len;
+    CandQ cq;
+    cq.slot = slots + wave * 64;
+    cq.ent = ents + wave * cand_cap_of(SRC_MFMA);
+    float best_t = __builtin_inff(); // in units of |d| during the scan
+    int best_id = -1;
+    SecClock sec;
+    sec.start();
+    scan_mfma(sc.mf_table, fr, o, dh, live, tmin * len, -1, lane, cq, sc.sph, best_t, best_id, sec);
+    if (!live) return;
+    best_t *= inv_len;
+    if (expanded) expanded[i] = 0;
+    id[i] = best_id;
+    if (best_id >= 0) {
+        Hit h = finish_hit(o, d, best_t, sc.sph[best_id]);
+        if (t) t[i] = best_t;
+        if (normal) { normal[3 * i] = h.n.x; normal[3 * i + 1] = h.n.y; normal[3 * i + 2] = h.n.z; }
+        if (front) front[i] = h.front ? 1 : 0;
+    } else {
+        if (t) t[i] = 0.f;
+        if (normal) { normal[3 * i] = 0.f; normal[3 * i + 1] = 0.f; normal[3 * i + 2] = 0.f; }
+        if (front) front[i] = 0;
+    }
+}
+
 // Batch scatter: the bounce step of the render kernel on explicit inputs.
 __global__ void scatter_kernel(int n, const DMat *__restrict__ mats, const uint32_t *__restrict__ mat,
                                const float *__restrict__ in_dir, const float *__restrict__ point,
@@ -2031,6 +2077,10 @@ RT_API int rt_first_hit_ex(rt_ctx *ctx, int n_rays, const float *d_org, const fl
     if (flags & RT_FH_REFINE)
         hipLaunchKernelGGL(first_hit_kernel<true>, grid, block, 0, st, n_rays, d_org, d_dir, tmin, sc, ctx->n_spheres,
                            ctx->n_prims, general, expanded_state, d_id, d_t, d_normal, d_front, d_expanded);
+    else if (!general && ctx->mf_usable && ctx->mf_wanted)
+        // the plain query runs the scan the render kernel runs on this scene
+        hipLaunchKernelGGL(first_hit_mfma_kernel, grid, block, 0, st, n_rays, d_org, d_dir, tmin, sc, ctx->mf, d_id, d_t,
+                           d_normal, d_front, d_expanded);
     else
         hipLaunchKernelGGL(first_hit_kernel<false>, grid, block, 0, st, n_rays, d_org, d_dir, tmin, sc,
                            ctx->n_spheres, ctx->n_prims, general, expanded_state, d_id, d_t, d_normal, d_front,

@@ -230,3 +230,39 @@ def test_strained_frames_drop_no_hit(name):
             os.environ["RT_AMD_SPHERE_SOURCE"] = old
     assert a[2] == b[2], f"ray counts differ: {a[2]} vs {b[2]}"
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("name", ["random_spheres", "offset", "radii", "streamed"])
+def test_plain_first_hit_runs_the_matrix_core_scan_and_agrees_with_double(name, oracle64):
+    """SceneManager::hitClosest (reference src/RayTracer.cpp:68-82) for rays of every kind -- aimed, grazing, starting
+    on surfaces, origins far out -- through the scan the render kernel runs (matrix-core filter, queue, exact
+    single-precision decision): the object id may differ from the double-precision oracle's only where the
+    oracle itself reports a marginal decision, and never because the filter dropped a sphere."""
+    scene = scenes.by_name(name) if name == "random_spheres" else _strain_scenes()[name]
+    rng = np.random.default_rng(23)
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        info = r.filter_describe()
+        assert info["in_use"]
+        org, d = _rays(scene, 30000, rng, spread=info["radius"])
+        far = rng.random(len(org)) < 0.05
+        org[far] = (info["center"] + (org[far] - info["center"]) * 100.0).astype(np.float32)
+        d[far] = (info["center"] + rng.normal(size=(far.sum(), 3)) * 0.3 * info["radius"] - org[far]).astype(np.float32)
+        ids, t, nrm, front = r.first_hit(org, d, tmin=np.float32(0.001), refine=False)
+        rid, rt, _, _ = r.first_hit(org, d, tmin=np.float32(0.001), refine=True)
+    oid, ot, onrm, ofront, margin = oracle64.first_hit(scene, org, d, tmin=float(np.float32(0.001)), want_margin=True)
+    assert np.array_equal(rid, oid)
+    bad = ids != oid
+    print(f"{name}: {len(oid)} rays, {int((oid >= 0).sum())} hits, {int(bad.sum())} ids differ from the double evaluation, "
+          f"largest margin among them {margin[bad].max() if bad.any() else 0.0:.2e}")
+    assert np.all(margin[bad] < 1e-5), f"unambiguous rays disagree: margins {np.sort(margin[bad])[-5:]}"
+    ok = (~bad) & (oid >= 0) & (margin >= 1e-3)
+    assert ok.sum() > 1000
+    # t: relative 1e-4, plus the resolution of single-precision positions at the scale of the ray and of the sphere it
+    # hits (the r = 1000 ground sphere is known to 6e-5), which grows like 1 / sqrt(margin) towards grazing incidence
+    dlen = np.linalg.norm(d.astype(np.float64), axis=1)
+    sp = _xyzr(scene)[np.maximum(oid, 0)]
+    reach = np.maximum(np.abs(org).max(axis=1), np.abs(sp[:, :3]).max(axis=1) + np.abs(sp[:, 3])) + np.abs(ot) * dlen
+    tol = 1e-4 * np.abs(ot) + 8 * np.finfo(np.float32).eps * reach / dlen / np.sqrt(np.minimum(margin, 1.0))
+    assert np.all(np.abs(t[ok] - ot[ok]) <= tol[ok]), np.max(np.abs(t[ok] - ot[ok]) / tol[ok])
+    assert np.array_equal(front[ok], ofront[ok])
