@@ -615,7 +615,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? 1 : 
         //      slot and go on, so the wave stays full until the queue is empty ----
         RT_SEC(4); // hand-out of new samples
         bool fresh = false;
-        int px = 0, py = 0;
+        int px = 0, py = 0, new_smp = 0;
         for (unsigned long long m = __ballot(pt.pix < 0); m != 0; m = __ballot(pt.pix < 0)) {
             if (!pool_open) {
                 if (queue_empty || (have0 && have1)) break;
@@ -665,13 +665,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? 1 : 
                     pt.pix = fill * SLOT_WORDS + (ly << KP.tile_w_log2) + lx;
                     px = tile.x0 + lx;
                     py = tile.y0 + ly;
-                    pt.gpix = rng_key((uint32_t)(py * KP.width + px));
-                    pt.sample = rng_key((uint32_t)(smp + KP.sample_offset));
-                    pt.call = rng_key(0u);
-                    pt.T = mk(1, 1, 1);
-                    pt.L = mk(0, 0, 0);
-                    pt.depth = KP.max_depth;
-                    pt.self_id = -1;
+                    new_smp = smp;
                     fresh = true;
                 }
             }
@@ -687,6 +681,17 @@ __global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? 1 : 
         // ---- the next ray of every lane that has one to make: a primary ray (Camera::genRay,
         //      src/Camera.cpp:124-135) or a bounce (RTMaterial::scatter); one random draw serves both ----
         RT_SEC(5); // random words, primary ray or scatter
+        if (fresh) {
+            // the path state of a new sample is set here, outside the hand-out loop: inside it every field
+            // would be carried around the loop's exits in register copies
+            pt.gpix = rng_key((uint32_t)(py * KP.width + px));
+            pt.sample = rng_key((uint32_t)(new_smp + KP.sample_offset));
+            pt.call = rng_key(0u);
+            pt.T = mk(1, 1, 1);
+            pt.L = mk(0, 0, 0);
+            pt.depth = KP.max_depth;
+            pt.self_id = -1;
+        }
         if (fresh || bounce) {
             uint32_t w0, w1, w2, w3;
             rng4_keyed(pt.gpix, pt.sample, pt.call, rng_key(KP.seed), w0, w1, w2, w3);
