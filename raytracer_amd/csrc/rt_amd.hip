@@ -454,13 +454,13 @@ __global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? 1 : 
         asm volatile("" : "+s"(kargs)); // launch parameters are fetched again from here on, not held across the scan
         RT_SEC(1);
         bool bounce = false;
-        // the hit and its material: set wherever `bounce` is, read only under it (no defaults: a default
-        // would be a register write per field and iteration for every lane)
         Hit h;
-        float4 at, ef;
-        float ior;
+        h.p = h.n = mk(0, 0, 0);
+        h.front = false;
+        float4 at = make_float4(0, 0, 0, 0), ef = make_float4(0, 0, 0, 0);
+        float ior = 1.f;
         int hit_mat = 0;
-        int next_self; // packed index of the sphere a diffuse / metal bounce starts on
+        int next_self = -1; // packed index of the sphere a diffuse / metal bounce starts on
         const bool shadow_ray = FULL && ls.light_i >= 0;
         if (active) {
             my_rays++;

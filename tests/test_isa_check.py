@@ -48,3 +48,16 @@ def test_loop_carried_load():
     loop = ".LBB0_1:\n" + WAIT + "\tv_mov_b32_e32 v0, s8\n" + LOAD + "{extra}\ts_cbranch_scc1 .LBB0_1\n" + WAIT
     assert check_isa.check(kernel(LOAD + loop.format(extra=""))) == []
     assert len(check_isa.check(kernel(LOAD + loop.format(extra="\ts_mov_b32 s20, s11\n")))) == 1
+
+
+def test_render_kernels_with_scratch_memory_are_refused():
+    """A render kernel that spills registers to scratch memory is reported; device functions that are
+    called rather than launched, and other kernels, are not."""
+    def info(kind, scratch):
+        return f"; {kind} info:\n; codeLenInByte = 8\n; NumVgprs: 96\n; ScratchSize: {scratch}\n; Occupancy: 5\n"
+    asm = ("\t.amdhsa_kernel _Z13render_kernelILi2ELb0EEv\n\t.end_amdhsa_kernel\n" + info("Kernel", 12) +
+           info("Function", 128) +
+           "\t.amdhsa_kernel _Z13render_kernelILi3ELb0EEv\n\t.end_amdhsa_kernel\n" + info("Kernel", 0) +
+           "\t.amdhsa_kernel _Z16first_hit_kernelILb1EEv\n\t.end_amdhsa_kernel\n" + info("Kernel", 256))
+    found = check_isa.scratch_users(asm)
+    assert len(found) == 1 and "ILi2ELb0" in found[0] and "12" in found[0]

@@ -9,6 +9,8 @@ assembly, follows every path of each kernel's control-flow graph, and fails if a
 can execute between such a load and the next inline-asm `s_waitcnt lgkmcnt(0)` touches one of the
 load's destination registers.
 
+It also refuses a build in which a render kernel spills registers to scratch memory (scratch_users).
+
 usage: check_isa.py [file.s]     (without a file: compiles raytracer_amd/csrc/rt_amd.hip to assembly first)
 """
 import os
@@ -120,8 +122,32 @@ def check(asm: str) -> list:
     return problems
 
 
+def scratch_users(asm: str) -> list:
+    """Render kernels that would need private scratch memory (register spills to memory).  The runtime allocates
+    that memory at launch, which the entry point that promises to allocate nothing cannot have, and a spill
+    inside the path loop is a memory access per iteration: a build with one is refused."""
+    found, name, in_kernel_info = [], None, False
+    for line in asm.splitlines():
+        m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        if line.startswith("; Kernel info:"):
+            in_kernel_info = True   # the block of the kernel named last
+        elif line.startswith("; Function info:"):
+            in_kernel_info = False  # a device function that is called, not launched
+        m = re.match(r";\s*ScratchSize:\s*(\d+)", line)
+        if m and in_kernel_info and name and "render_kernel" in name and int(m.group(1)) > 0:
+            found.append(f"{name}: ScratchSize {m.group(1)}")
+    return found
+
+
 def main() -> int:
     asm = open(sys.argv[1]).read() if len(sys.argv) > 1 else device_asm()
+    spilled = scratch_users(asm)
+    for s in spilled:
+        print("render kernel with scratch memory:", s)
+    if spilled and not os.environ.get("RT_ALLOW_SCRATCH"):  # tuning builds (-DRT_STATS ...) may set this
+        return 1
     problems = check(asm)
     for p in problems[:40]:
         print("ISA hazard:", p)
