@@ -86,9 +86,21 @@ __device__ __forceinline__ unsigned long long to_fixed_magnitude(float x) {
 // The three channels of one sample.  Radiance is hardly ever negative (it takes a negative emission or
 // albedo), so the sign is applied on a path of its own that a wave enters only if one of its lanes needs it.
 __device__ __forceinline__ void to_fixed3(V3 L, unsigned long long &fx, unsigned long long &fy, unsigned long long &fz) {
-    fx = to_fixed_magnitude(L.x);
-    fy = to_fixed_magnitude(L.y);
-    fz = to_fixed_magnitude(L.z);
+    // the clamped magnitudes (a NaN becomes 0)
+    const float mx = fminf(fmaxf(fabsf(L.x), 0.0f), 1073741824.0f), my = fminf(fmaxf(fabsf(L.y), 0.0f), 1073741824.0f),
+                mz = fminf(fmaxf(fabsf(L.z), 0.0f), 1073741824.0f);
+    if (__ballot(fmaxf(fmaxf(mx, my), mz) >= 256.0f) == 0) {
+        // the usual case, radiance below 256 in every lane: m * 2^24 is exact in a float and fits 32 bits, and
+        // its truncation is the same number to_fixed_magnitude() assembles from integer and fractional part
+        fx = (unsigned long long)(unsigned)(mx * 16777216.0f);
+        fy = (unsigned long long)(unsigned)(my * 16777216.0f);
+        fz = (unsigned long long)(unsigned)(mz * 16777216.0f);
+    } else {
+        asm volatile(""); // keeps this a branch
+        fx = to_fixed_magnitude(L.x);
+        fy = to_fixed_magnitude(L.y);
+        fz = to_fixed_magnitude(L.z);
+    }
     if (__ballot(fminf(fminf(L.x, L.y), L.z) < 0.0f)) {
         asm volatile(""); // keeps this a branch: folded into selects it would run for every sample
         fx = L.x < 0.0f ? 0ull - fx : fx;
