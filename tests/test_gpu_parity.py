@@ -227,6 +227,32 @@ def test_render_converged_parity(renderer, oracle64, scene_name, W, H, spp, dept
     assert oracle64.refract_clamped() == 0
 
 
+def test_very_bright_and_negative_radiance_sums(renderer, oracle64):
+    """The radiance sums are kept in 40.24 fixed point with a short conversion for samples below 256; an emitter
+    far brighter than that, and one with negative emission (RTMaterial::emitted() is a plain public value,
+    reference inc/RTMaterial.h:34-37), take the full conversion and its sign handling: the sums still equal
+    the oracle's double sums to single-precision rounding of the samples."""
+    b = scenes._Builder()
+    b.sphere((0.0, -100.5, 3.0), 100.0, b.lambertian((0.8, 0.8, 0.0)))
+    b.sphere((0.0, 0.0, 3.0), 0.5, b.lambertian((0.1, 0.2, 0.5)))
+    b.sphere((-1.0, 0.0, 3.0), 0.5, b.metal((0.8, 0.6, 0.2), 0.3))
+    b.sphere((1.0, 0.4, 3.0), 0.35, b.emissive((5000.0, 300.0, 0.5)))
+    b.sphere((0.0, 1.2, 3.0), 0.3, b.emissive((-2.0, -0.5, -300.0)))
+    scene = b.build("bright", scenes.make_camera())
+    renderer.set_scene(scene)
+    W, H, spp = 96, 54, 64
+    rgba, accum, rays = renderer.render_host(RenderParams(W, H, samples_per_pixel=spp, max_depth=8, seed=4), want_accum=True)
+    orgba, oacc, orays = oracle64.render(scene, W, H, spp, 8, seed=4)
+    assert abs(rays - orays) <= 2e-3 * orays
+    assert accum[:, :, :3].max() > 256.0 * 4 and accum[:, :, :3].min() < -10.0  # both special cases occur
+    # per pixel: equal to the oracle's sum within rounding, except where single precision sent a path another way
+    err = np.abs(accum[:, :, :3] - oacc) / (1.0 + np.abs(oacc))
+    assert np.mean(err > 1e-4) < 0.02, np.mean(err > 1e-4)
+    # over the frame the differing paths average out
+    assert np.allclose(accum[:, :, :3].sum(axis=(0, 1)), oacc.sum(axis=(0, 1)), rtol=2e-3)
+    assert_same_streams(rgba[:, :, :3], orgba[:, :, :3], "bright")
+
+
 def test_render_is_reproducible_and_partition_invariant(renderer):
     scene = scenes.random_spheres_scene()
     renderer.set_scene(scene)
