@@ -62,11 +62,21 @@ constexpr size_t MF_LDS_BYTES = 159 * 1024; // dynamic LDS a workgroup of the ma
 #ifndef RT_MF_STREAM_THREADS
 #define RT_MF_STREAM_THREADS 1024
 #endif
-constexpr int wg_threads_of(int src) { return src == SRC_MFMA ? 1024 : src == SRC_MFMA_STREAMED ? RT_MF_STREAM_THREADS : WG_THREADS; }
+// The general kernel (lights, other primitive kinds, the halo) carries more state per path: its matrix-core
+// variant gets three waves per SIMD (170 registers each) in a workgroup of twelve.
+#ifndef RT_MF_FULL_THREADS
+#define RT_MF_FULL_THREADS 768
+#endif
+constexpr int wg_threads_of(int src, bool full = false) {
+    return src == SRC_MFMA ? (full ? RT_MF_FULL_THREADS : 1024) : src == SRC_MFMA_STREAMED ? RT_MF_STREAM_THREADS : WG_THREADS;
+}
 constexpr int cand_cap_of(int src) { return is_mfma(src) ? 128 : CAND_CAP; }
-constexpr size_t acc_bytes_of(int src) { return (size_t)(wg_threads_of(src) / 64) * WAVE_LDS_WORDS * sizeof(unsigned long long); }
-constexpr size_t wave_state_bytes_of(int src) {
-    return acc_bytes_of(src) + (size_t)(wg_threads_of(src) / 64) * (cand_cap_of(src) * sizeof(unsigned) + 64 * sizeof(unsigned long long));
+constexpr size_t acc_bytes_of(int src, bool full = false) {
+    return (size_t)(wg_threads_of(src, full) / 64) * WAVE_LDS_WORDS * sizeof(unsigned long long);
+}
+constexpr size_t wave_state_bytes_of(int src, bool full = false) {
+    return acc_bytes_of(src, full) +
+           (size_t)(wg_threads_of(src, full) / 64) * (cand_cap_of(src) * sizeof(unsigned) + 64 * sizeof(unsigned long long));
 }
 static_assert(wave_state_bytes_of(SRC_SCALAR) == WAVE_STATE_BYTES, "the plain variants keep their layout");
 
@@ -329,8 +339,8 @@ template <int SRC, bool FULL>
 #ifndef RT_FULL_MIN_WAVES
 #define RT_FULL_MIN_WAVES 1
 #endif
-__global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? RT_FULL_MIN_WAVES : 5)) void render_kernel(KArgs args) {
-    constexpr int WGT = wg_threads_of(SRC), NW = WGT / 64;
+__global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 : 4) : (FULL ? RT_FULL_MIN_WAVES : 5)) void render_kernel(KArgs args) {
+    constexpr int WGT = wg_threads_of(SRC, FULL), NW = WGT / 64;
     // The scan needs 64 SGPRs for sphere words, so whatever else lives in SGPRs across it is spilled
     // into VGPR lanes and comes back through v_readlane, which costs VALU issue slots, the kernel's
     // bottleneck.  The launch parameters are therefore read from the kernel-argument segment (constant
@@ -348,8 +358,8 @@ __global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? RT_F
     // per-wave state first (two accumulator slots of 3 channels x 64 pixels and their tile
     // descriptors), then the sphere words
     unsigned long long *acc_all = reinterpret_cast<unsigned long long *>(smem);
-    float4 *lds_sph = reinterpret_cast<float4 *>(smem + wave_state_bytes_of(SRC));
-    uint4v *lds_tab = reinterpret_cast<uint4v *>(smem + wave_state_bytes_of(SRC)); // the matrix-core variants' table / tiles
+    float4 *lds_sph = reinterpret_cast<float4 *>(smem + wave_state_bytes_of(SRC, FULL));
+    uint4v *lds_tab = reinterpret_cast<uint4v *>(smem + wave_state_bytes_of(SRC, FULL)); // the matrix-core variants' table / tiles
     // the squared radii follow the pair words of the resident list / of one streamed tile
     float4 *lds_r2 = lds_sph + 4 * (SRC == SRC_LDS_STREAMED ? STREAM_QUADS : KP.n_quads);
 
@@ -358,8 +368,8 @@ __global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? RT_F
     unsigned long long *acc = acc_all + wave * WAVE_LDS_WORDS;
     int *desc = reinterpret_cast<int *>(acc + 2 * SLOT_WORDS); // slot s: desc[8 s ...] = x0, y0, vw, vh, row0
     CandQ cq;
-    cq.slot = reinterpret_cast<unsigned long long *>(smem + acc_bytes_of(SRC)) + wave * 64;
-    cq.ent = reinterpret_cast<unsigned *>(smem + acc_bytes_of(SRC) + NW * 64 * sizeof(unsigned long long)) + wave * cand_cap_of(SRC);
+    cq.slot = reinterpret_cast<unsigned long long *>(smem + acc_bytes_of(SRC, FULL)) + wave * 64;
+    cq.ent = reinterpret_cast<unsigned *>(smem + acc_bytes_of(SRC, FULL) + NW * 64 * sizeof(unsigned long long)) + wave * cand_cap_of(SRC);
 
     const int nquads = KP.n_quads; // groups of four spheres, padding included
     if (SRC == SRC_LDS_RESIDENT) {
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC), is_mfma(SRC) ? 4 : (FULL ? RT_F
         for (int i = threadIdx.x; i < nquads; i += WGT) lds_r2[i] = KS.r2q[i];
     }
     if (SRC == SRC_MFMA) {
-        uint4v *dst = reinterpret_cast<uint4v *>(smem + wave_state_bytes_of(SRC));
+        uint4v *dst = reinterpret_cast<uint4v *>(smem + wave_state_bytes_of(SRC, FULL));
         for (int i = threadIdx.x; i < (KP.mf.n_blocks + 1) * MF_BLOCK_WORDS; i += WGT) dst[i] = KS.mf_table[i];
     }
     __syncthreads();
@@ -1280,7 +1290,9 @@ struct rt_ctx {
     MfmaFrame mf{};
     bool mf_usable = false;  // the scene has a table and it fits in LDS
     bool mf_wanted = true;   // RT_AMD_SPHERE_SOURCE did not ask for another source
+    bool mf_full_ok = true;  // the device accepted the LDS budget of the general kernel's matrix-core variant
     int mf_resident = 0;     // workgroups of the scene's matrix-core variant a CU holds (queried at upload)
+    int mf_resident_full = 0; // the same for the general kernel's variant (0: its table does not fit, or no such device)
     unsigned char *d_queue = nullptr; // ring of work-item counters of the persistent render kernel
     unsigned queue_next = 0;          // next slot of the ring
     unsigned char *d_scratch = nullptr; // this device's copy of `scratch` (rt_render_noalloc)
@@ -1507,6 +1519,11 @@ RT_API int rt_create(int device, rt_ctx **out) {
         (void)hipGetLastError();
         ctx->mf_wanted = false;
     }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_MFMA, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)MF_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->mf_full_ok = false;
+    }
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_MFMA_STREAMED, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)MF_LDS_BYTES) != hipSuccess) {
         (void)hipGetLastError();
@@ -1613,7 +1630,9 @@ struct MfTable {
 };
 
 // LDS the matrix-core variants need: the whole table (plus the block the read-ahead touches), or two tiles
-size_t mf_lds_resident(int n_blocks) { return wave_state_bytes_of(SRC_MFMA) + (size_t)(n_blocks + 1) * MF_BLOCK_WORDS * 16; }
+size_t mf_lds_resident(int n_blocks, bool full = false) {
+    return wave_state_bytes_of(SRC_MFMA, full) + (size_t)(n_blocks + 1) * MF_BLOCK_WORDS * 16;
+}
 constexpr size_t MF_LDS_STREAMED = wave_state_bytes_of(SRC_MFMA_STREAMED) + 2 * (size_t)MF_TILE_WORDS * 16;
 static_assert(MF_LDS_STREAMED <= MF_LDS_BYTES, "two tiles and the wave state fit in LDS");
 
@@ -1828,6 +1847,16 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
             resident = 0;
         (void)hipGetLastError();
         ctx->mf_resident = resident;
+        // the general kernel takes the table only when it stays resident in LDS beside the larger path state
+        int resident_full = 0;
+        if (ctx->mf_full_ok && mf_lds_resident(mft.fr.n_blocks, true) <= MF_LDS_BYTES &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_full,
+                                                         reinterpret_cast<const void *>(&render_kernel<SRC_MFMA, true>),
+                                                         wg_threads_of(SRC_MFMA, true),
+                                                         mf_lds_resident(mft.fr.n_blocks, true)) != hipSuccess)
+            resident_full = 0;
+        (void)hipGetLastError();
+        ctx->mf_resident_full = resident_full;
         ctx->mf_usable = resident >= 1; // a device that cannot hold the workgroup scans with the packed filter
     }
     if ((rc = to_device(ctx, &ctx->d_mat_id, mid)) != RT_OK) return rc;
@@ -1980,24 +2009,26 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
         src = resident ? SRC_LDS_RESIDENT : SRC_LDS_STREAMED;
         lds += (size_t)(resident ? (ctx->n_quads > 0 ? ctx->n_quads : 1) : STREAM_QUADS) * 5 * sizeof(float4);
     }
-    if (ctx->mf_usable && ctx->mf_wanted && !full) {
+    // the general kernel's long sphere lists go through the matrix-core filter too when the table stays resident
+    const bool mf_full = full && ctx->mf_resident_full >= 1 && ctx->n_spheres >= FULL_SCALAR_MIN_SPHERES;
+    if (ctx->mf_usable && ctx->mf_wanted && (!full || mf_full)) {
         // matrix-core filter: one table per workgroup in LDS, as many workgroups as stay resident
-        const bool fits = mf_lds_resident(ctx->mf.n_blocks) <= MF_LDS_BYTES;
+        const bool fits = full || mf_lds_resident(ctx->mf.n_blocks) <= MF_LDS_BYTES;
         src = fits ? SRC_MFMA : SRC_MFMA_STREAMED;
         k.mf = ctx->mf;
-        lds = fits ? mf_lds_resident(ctx->mf.n_blocks) : MF_LDS_STREAMED;
-        const int resident = ctx->mf_resident;
-        const int wpw = wg_threads_of(src) / 64;
+        lds = fits ? mf_lds_resident(ctx->mf.n_blocks, full) : MF_LDS_STREAMED;
+        const int resident = full ? ctx->mf_resident_full : ctx->mf_resident;
+        const int wpw = wg_threads_of(src, full) / 64;
         want = (items + wpw - 1) / wpw;
         cap = (long long)ctx->n_cus * resident;
         grid = dim3((unsigned)(want < cap ? want : cap));
-        block = dim3(wg_threads_of(src));
+        block = dim3(wg_threads_of(src, full));
     } else {
         memset(&k.mf, 0, sizeof k.mf);
     }
     const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, queue};
 #define RT_LAUNCH(S, L) hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, ka)
-    if (src == SRC_MFMA) RT_LAUNCH(SRC_MFMA, false);
+    if (src == SRC_MFMA) { if (full) RT_LAUNCH(SRC_MFMA, true); else RT_LAUNCH(SRC_MFMA, false); }
     else if (src == SRC_MFMA_STREAMED) RT_LAUNCH(SRC_MFMA_STREAMED, false);
     else if (src == SRC_SCALAR) { if (full) RT_LAUNCH(SRC_SCALAR, true); else RT_LAUNCH(SRC_SCALAR, false); }
     else if (src == SRC_LDS_RESIDENT) { if (full) RT_LAUNCH(SRC_LDS_RESIDENT, true); else RT_LAUNCH(SRC_LDS_RESIDENT, false); }

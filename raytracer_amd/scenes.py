@@ -218,7 +218,7 @@ class _Lcg:
         return lo + (hi - lo) * self.u()
 
 
-def random_spheres_scene(seed: int = 12345) -> Scene:
+def random_spheres_scene(seed: int = 12345, lit: bool = False, floor: bool = False) -> Scene:
     """The RTOW "final scene" turned z-up: RTOW (x, y, z) -> (x, -z, y)."""
     g = _Lcg(seed)
     b = _Builder()
@@ -243,7 +243,21 @@ def random_spheres_scene(seed: int = 12345) -> Scene:
     b.sphere((0.0, 0.0, 1.0), 1.0, b.dielectric((1.0, 1.0, 1.0), 1.5))
     b.sphere((-4.0, 0.0, 1.0), 1.0, b.lambertian((0.4, 0.2, 0.1)))
     b.sphere((4.0, 0.0, 1.0), 1.0, b.metal((0.7, 0.6, 0.5), 0.0))
-    return b.build("random_spheres", make_camera((13.0, -3.0, 2.0), (-13.0, 3.0, -2.0)))
+    name = "random_spheres"
+    if lit:
+        # two Phong point lights above the field: every hit then sends a shadow query per light
+        # (Camera::computeDirectLighting, reference src/Camera.cpp:161-178)
+        b.light((6.0, -4.0, 8.0), (0.03, 0.03, 0.03), (0.5, 0.5, 0.45), (0.8, 0.8, 0.8), 24.0)
+        b.light((-8.0, 5.0, 6.0), (0.02, 0.02, 0.03), (0.25, 0.3, 0.4), (0.5, 0.5, 0.5), 12.0)
+        name = "random_spheres_lit"
+    if floor:
+        # a ground plane instead of relying on the big sphere alone, and one selected sphere: the general kernel
+        # with a long sphere list
+        b.plane((0.0, 0.0, -0.001), (0.0, 0.0, 1.0), b.lambertian((0.45, 0.5, 0.45)))
+        b.cube((2.0, -2.5, 0.5), (0.5, 0.5, 0.5), b.metal((0.8, 0.7, 0.6), 0.05))
+        b.select(10)
+        name += "_floor"
+    return b.build(name, make_camera((13.0, -3.0, 2.0), (-13.0, 3.0, -2.0)))
 
 
 def halo_overlap_scene() -> Scene:
@@ -340,6 +354,12 @@ def by_name(name: str) -> Scene:
         return mixed_scene(selected=True)
     if name == "mixed_lit":
         return mixed_scene(selected=True, phong=1)
+    if name == "random_spheres_lit":
+        return random_spheres_scene(lit=True)
+    if name == "random_spheres_floor":
+        return random_spheres_scene(floor=True)
+    if name == "random_spheres_lit_floor":
+        return random_spheres_scene(lit=True, floor=True)
     if name == "halo_overlap":
         return halo_overlap_scene()
     if name == "random_spheres":

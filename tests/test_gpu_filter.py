@@ -266,3 +266,36 @@ def test_plain_first_hit_runs_the_matrix_core_scan_and_agrees_with_double(name, 
     tol = 1e-4 * np.abs(ot) + 8 * np.finfo(np.float32).eps * reach / dlen / np.sqrt(np.minimum(margin, 1.0))
     assert np.all(np.abs(t[ok] - ot[ok]) <= tol[ok]), np.max(np.abs(t[ok] - ot[ok]) / tol[ok])
     assert np.array_equal(front[ok], ofront[ok])
+
+
+@pytest.mark.parametrize("name", ["random_spheres_lit", "random_spheres_floor", "random_spheres_lit_floor"])
+def test_general_kernel_with_a_long_sphere_list_takes_the_matrix_core_filter(name, oracle64, monkeypatch):
+    """Lights (Camera::computeDirectLighting, reference src/Camera.cpp:161-178: a shadow query per light and hit),
+    other primitive kinds and the selection halo run in the general kernel; with 485 spheres its sphere scan is the
+    matrix-core filter too.  Same bytes and ray count as with the packed filter, and the oracle's image."""
+    from raytracer_amd.api import FLAG_DIRECT_LIGHT
+
+    scene = scenes.by_name(name)
+    lit = scene.lights is not None and len(scene.lights) > 0
+    W, H, spp, depth = 112, 64, 24, 12
+    p = RenderParams(W, H, spp, depth, seed=9, flags=FLAG_DIRECT_LIGHT if lit else 0)
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        assert r.filter_describe()["in_use"]
+        a = r.render_host(p, want_accum=True)
+        ms_mfma = r.last_kernel_ms()
+    monkeypatch.setenv("RT_AMD_SPHERE_SOURCE", "scalar")
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        assert not r.filter_describe()["in_use"]
+        b = r.render_host(p, want_accum=True)
+        ms_packed = r.last_kernel_ms()
+    assert a[2] == b[2], f"ray counts differ: {a[2]} vs {b[2]}"
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    ref, _, ref_rays = oracle64.render(scene, W, H, spp, depth, seed=9, direct_light=lit)
+    diff = a[0][:, :, :3].astype(np.int32) - ref[:, :, :3].astype(np.int32)
+    close = float(np.mean(np.abs(diff) <= 1))
+    print(f"{name}: kernel {ms_mfma:.2f} ms (packed filter {ms_packed:.2f} ms), rays {a[2]} vs oracle {ref_rays}, "
+          f"{100 * close:.2f} % of bytes within 1 of the oracle's")
+    assert close >= 0.99
+    assert abs(a[2] - ref_rays) <= 4e-3 * ref_rays
