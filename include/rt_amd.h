@@ -316,9 +316,8 @@ void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint
  * (src/Camera.cpp:84,129-130; inc/RTMaterial.h:72,111,158). */
 int rt_rng4_device_host(rt_ctx *ctx, int n, const uint32_t *h_keys, uint32_t *h_out);
 
-/* The sphere filter of the matrix-core scan, exposed for tests.  Scenes of more than 8 and up to about
- * 1400 spheres are scanned by a conservative filter evaluated on the matrix cores (every sphere a ray
- * could hit passes; what passes is decided exactly), in a frame centred on the sphere cloud; spheres much
+/* The sphere filter of the matrix-core scan, exposed for tests.  Scenes of 16 spheres and more are scanned by
+ * a conservative filter evaluated on the matrix cores (every sphere a ray could hit passes; what passes is decided exactly), in a frame centred on the sphere cloud; spheres much
  * larger than the cloud are kept out of it and decided directly.  No counterpart in the reference: it is
  * SceneManager::hitClosest's loop over all objects (src/RayTracer.cpp:77-82) in another arithmetic. */
 typedef struct rt_filter_info {

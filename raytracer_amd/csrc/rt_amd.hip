@@ -42,6 +42,8 @@ constexpr int WAVES_PER_WG = 4;
 constexpr int MAX_TILE_PX = 64;              // largest pixel tile a work item may cover (8 x 8)
 constexpr int RESIDENT_MAX = 4096;           // spheres kept resident in LDS (80 KiB)
 constexpr int SMALL_SCENE = 8;               // up to this many spheres the scalar-load scan decides every sphere directly
+constexpr int MF_MIN_SPHERES = 16;           // scenes get a matrix-core filter table from this many spheres on (measured: the packed
+                                             // filter is 8 % ahead at 9 and 12 spheres, even at 16, 7 % behind at 24, 24 % at 64)
 constexpr int FULL_SCALAR_MIN_SPHERES = 128;  // the general kernel takes sphere words from LDS below this many spheres
 constexpr int STREAM_QUADS = 512;            // quads (4 spheres, 80 B) per streamed LDS tile (40 KiB)
 constexpr int SLOT_WORDS = 3 * MAX_TILE_PX;  // one tile slot's accumulators: r, g, b planes of 64-bit sums
@@ -1292,6 +1294,7 @@ struct rt_ctx {
     bool mf_wanted = true;   // RT_AMD_SPHERE_SOURCE did not ask for another source
     bool mf_full_ok = true;  // the device accepted the LDS budget of the general kernel's matrix-core variant
     int mf_resident = 0;     // workgroups of the scene's matrix-core variant a CU holds (queried at upload)
+    int mf_full_min = 24; // sphere count from which the general kernel takes the table (measured: even at 16, 5 % ahead at 32, 26 % at 64; tuning: RT_AMD_MF_FULL_MIN)
     int mf_resident_full = 0; // the same for the general kernel's variant (0: its table does not fit, or no such device)
     unsigned char *d_queue = nullptr; // ring of work-item counters of the persistent render kernel
     unsigned queue_next = 0;          // next slot of the ring
@@ -1543,6 +1546,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
     if (const char *w = getenv("RT_AMD_WGS_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 64) ctx->wgs_per_cu = v; }
     // where the scan takes sphere data from: scalar loads (default, fastest measured) or LDS
     // broadcast reads ("lds": resident copy for small scenes, streamed tiles for large ones)
+    if (const char *t = getenv("RT_AMD_MF_FULL_MIN")) { int v = atoi(t); if (v >= MF_MIN_SPHERES) ctx->mf_full_min = v; }
     if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (v >= 0 && v <= 3) ctx->force_tile = v; }
     const char *src = getenv("RT_AMD_SPHERE_SOURCE");
     ctx->scalar_source = !(src && strcmp(src, "lds") == 0);
@@ -1640,7 +1644,7 @@ MfTable build_mf_table(const std::vector<float4> &sph) {
     MfTable T;
     memset(&T.fr, 0, sizeof T.fr);
     const int n = (int)sph.size();
-    if (n <= SMALL_SCENE) return T;
+    if (n < MF_MIN_SPHERES) return T;
     for (const float4 &s : sph)
         if (!std::isfinite(s.x) || !std::isfinite(s.y) || !std::isfinite(s.z) || !std::isfinite(s.w)) return T;
     std::vector<char> big((size_t)n, 0);
@@ -2010,7 +2014,7 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
         lds += (size_t)(resident ? (ctx->n_quads > 0 ? ctx->n_quads : 1) : STREAM_QUADS) * 5 * sizeof(float4);
     }
     // the general kernel's long sphere lists go through the matrix-core filter too when the table stays resident
-    const bool mf_full = full && ctx->mf_resident_full >= 1 && ctx->n_spheres >= FULL_SCALAR_MIN_SPHERES;
+    const bool mf_full = full && ctx->mf_resident_full >= 1 && ctx->n_spheres >= ctx->mf_full_min;
     if (ctx->mf_usable && ctx->mf_wanted && (!full || mf_full)) {
         // matrix-core filter: one table per workgroup in LDS, as many workgroups as stay resident
         const bool fits = full || mf_lds_resident(ctx->mf.n_blocks) <= MF_LDS_BYTES;

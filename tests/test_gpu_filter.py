@@ -165,8 +165,8 @@ def _strain_scenes():
         # nested shells around one point and a row of spheres on a line: degenerate clouds
         "shells": _cloud("shells", 0, 4, extra=[((0.0, 0.0, 0.0), 0.1 * (k + 1)) for k in range(20)]),
         "row": _cloud("row", 0, 5, extra=[((0.9 * k - 18.0, 0.0, 0.0), 0.4) for k in range(40)]),
-        # the smallest table (one more sphere than the direct decision takes) and one streamed through LDS in tiles
-        "nine": _cloud("nine", 9, 6),
+        # the smallest scene that gets a table and one streamed through LDS in tiles
+        "sixteen": _cloud("sixteen", 16, 6),
         "streamed": _cloud("streamed", 2600, 7, box=(30.0, 30.0, 4.0), radii=(0.1, 0.5)),
         # the largest table that stays resident in LDS (46 blocks of 32) and the first that does not
         "edge_resident": _cloud("edge_resident", 1472, 8, box=(25.0, 25.0, 4.0), radii=(0.1, 0.5)),
@@ -174,7 +174,7 @@ def _strain_scenes():
     }
 
 
-@pytest.mark.parametrize("name", ["offset", "radii", "many_big", "shells", "row", "nine", "streamed", "edge_resident",
+@pytest.mark.parametrize("name", ["offset", "radii", "many_big", "shells", "row", "sixteen", "streamed", "edge_resident",
                                   "edge_streamed"])
 def test_strained_frames_drop_no_hit(name):
     """The superset property on scenes that stress how the filter's frame is chosen, with origins up to 10^4
