@@ -39,6 +39,9 @@ namespace {
 
 constexpr int WG_THREADS = 256;
 constexpr int WAVES_PER_WG = 4;
+#ifndef RT_ITEM_SAMPLES
+#define RT_ITEM_SAMPLES 1024 // a work item is the smallest tile shape that holds this many samples
+#endif
 constexpr int MAX_TILE_PX = 64;              // largest pixel tile a work item may cover (8 x 8)
 constexpr int RESIDENT_MAX = 4096;           // spheres kept resident in LDS (80 KiB)
 constexpr int SMALL_SCENE = 8;               // up to this many spheres the scalar-load scan decides every sphere directly
@@ -1547,7 +1550,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
     // where the scan takes sphere data from: scalar loads (default, fastest measured) or LDS
     // broadcast reads ("lds": resident copy for small scenes, streamed tiles for large ones)
     if (const char *t = getenv("RT_AMD_MF_FULL_MIN")) { int v = atoi(t); if (v >= MF_MIN_SPHERES) ctx->mf_full_min = v; }
-    if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (v >= 0 && v <= 3) ctx->force_tile = v; }
+    if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (*t >= '0' && *t <= '9' && v <= 6) ctx->force_tile = v; }
     const char *src = getenv("RT_AMD_SPHERE_SOURCE");
     ctx->scalar_source = !(src && strcmp(src, "lds") == 0);
     ctx->mf_wanted = ctx->mf_wanted && !(src && (strcmp(src, "lds") == 0 || strcmp(src, "scalar") == 0));
@@ -1957,20 +1960,22 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
     k.flags = p->flags;
     k.strip_first = p->strip_first;
     k.strip_stride = p->strip_stride;
-    // Work-item tiles: the smallest shape that still holds about five hundred samples.  Small items
-    // keep the longest one short (a tile whose every path runs to the depth limit costs 25 times
-    // the average, and the kernel cannot end before its last item does); much smaller ones would
-    // run dry before the long paths of the tile before them have ended, and a wave holds only
-    // two tiles (measured on 1200x675: 100 samples per item 3.5x slower, 400 to 1600 best).  The shape depends on the sample count only,
-    // never on the frame or the strip partition: the order in which a pixel's samples are summed
-    // follows from its tile, and any partition must produce the same bytes.
+    // Work-item tiles: the smallest of seven shapes (1x1 ... 8x8 pixels) that holds RT_ITEM_SAMPLES samples.  Small
+    // items keep the longest one short (a tile whose every path runs to the depth limit costs 25 times the
+    // average, and the kernel cannot end before its last item does); much smaller ones run dry before the long
+    // paths of the tile before them have ended (a wave holds only two tiles), and every item costs a trip to the
+    // global counter, a descriptor and a partial-sector store.  Measured: 100 samples per pixel 800 / 1600 / 3200
+    // samples per item 4.65 / 4.32 / 5.12 ms; 500 per pixel 500 / 1000 / 2000 / 4000 per item 26.97 / 26.42 /
+    // 26.51 / 28.49 ms; 1000 per pixel 1000 / 2000 / 4000 per item 551.9 / 547.0 / 546.0 ms; 256 per pixel on
+    // 10 001 spheres 512 / 1024 / 2048 / 4096 per item 4689 / 4684 / 4722 / 4750 ms.  The radiance sums are exact
+    // integers, so the shape changes no byte.
     int nstrips = local_strips(p);
     if (nstrips == 0) return RT_OK;
     {
-        static const int shapes[4][2] = {{0, 0}, {1, 1}, {2, 2}, {3, 3}}; // 1x1, 2x2, 4x4, 8x8 (log2)
+        static const int shapes[7][2] = {{0, 0}, {1, 0}, {1, 1}, {2, 1}, {2, 2}, {3, 2}, {3, 3}}; // 1x1, 2x1, 2x2 ... 8x8 (log2 w, h)
         const int spp = p->samples_per_pixel;
         int pick = 0;
-        while (pick < 3 && ((long long)spp << (shapes[pick][0] + shapes[pick][1])) < 480) ++pick;
+        while (pick < 6 && ((long long)spp << (shapes[pick][0] + shapes[pick][1])) < RT_ITEM_SAMPLES) ++pick;
         if (ctx->force_tile >= 0) pick = ctx->force_tile;
         k.tile_w_log2 = shapes[pick][0];
         k.tile_h_log2 = shapes[pick][1];
