@@ -1303,7 +1303,7 @@ struct rt_ctx {
     unsigned queue_next = 0;          // next slot of the ring
     unsigned char *d_scratch = nullptr; // this device's copy of `scratch` (rt_render_noalloc)
     int n_cus = 256;
-    int wgs_per_cu = 8;
+    int wgs_per_cu = 4; // workgroups of four waves per CU in the persistent grid (measured: 4 / 5 / 8 give 4.18 / 4.22 / 4.27 ms on the four-sphere scene, no difference elsewhere)
     int force_tile = -1; // tuning: 0 = 1x1, 1 = 2x2, 2 = 4x4, 3 = 8x8 work-item tiles
     uint32_t *d_mat_id = nullptr;
     DMat *d_mats = nullptr;
