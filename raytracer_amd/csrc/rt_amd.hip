@@ -341,10 +341,13 @@ __device__ __forceinline__ Tile decode_item(const P &p, unsigned item) {
 // short.  Inside a tile the wave runs the path loop described at the top of this file.
 template <int SRC, bool FULL>
 // the sphere-only variants are held to the register budget of five waves per SIMD
+#ifndef RT_SPHERE_MIN_WAVES
+#define RT_SPHERE_MIN_WAVES 5
+#endif
 #ifndef RT_FULL_MIN_WAVES
 #define RT_FULL_MIN_WAVES 1
 #endif
-__global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 : 4) : (FULL ? RT_FULL_MIN_WAVES : 5)) void render_kernel(KArgs args) {
+__global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 : 4) : (FULL ? RT_FULL_MIN_WAVES : RT_SPHERE_MIN_WAVES)) void render_kernel(KArgs args) {
     constexpr int WGT = wg_threads_of(SRC, FULL), NW = WGT / 64;
     // The scan needs 64 SGPRs for sphere words, so whatever else lives in SGPRs across it is spilled
     // into VGPR lanes and comes back through v_readlane, which costs VALU issue slots, the kernel's
