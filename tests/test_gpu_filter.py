@@ -299,3 +299,18 @@ def test_general_kernel_with_a_long_sphere_list_takes_the_matrix_core_filter(nam
           f"{100 * close:.2f} % of bytes within 1 of the oracle's")
     assert close >= 0.99
     assert abs(a[2] - ref_rays) <= 4e-3 * ref_rays
+
+
+def test_single_ray_queries_through_the_table(oracle64):
+    """SceneManager::hitClosest is asked one ray at a time by interactive callers (picking): a batch of one, of 63
+    and of 65 rays through the matrix-core scan, where most lanes of a wave carry no ray."""
+    scene = scenes.by_name("random_spheres")
+    org, d = oracle64.primary_rays(scene.camera, 13, 5)
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        assert r.filter_describe()["in_use"]
+        for n in (1, 63, 65):
+            ids, t, nrm, front = r.first_hit(org[:n], d[:n], tmin=np.float32(0.001), refine=False)
+            oid, ot, _, ofront, _ = oracle64.first_hit(scene, org[:n], d[:n], tmin=float(np.float32(0.001)))
+            assert np.array_equal(ids, oid) and np.array_equal(front[oid >= 0], ofront[oid >= 0])
+            assert np.allclose(t[oid >= 0], ot[oid >= 0], rtol=1e-4)
