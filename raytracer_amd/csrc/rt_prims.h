@@ -59,6 +59,9 @@ struct Closest {
     bool expanded;  // HitRecord::hitExpanded
 };
 
+// Quotients below are products with v_rcp_f32 (1 ulp): a correctly rounded single-precision quotient is an
+// eleven-instruction sequence, and these tests run for every ray and primitive.
+
 // "first primitive in insertion order reaching the smallest t wins" (strict < in
 // SceneManager::hitClosest, src/RayTracer.cpp:77-82) as an order-free rule
 __device__ __forceinline__ bool beats(float t, int prim, const Closest &c) {
@@ -74,7 +77,7 @@ __device__ __forceinline__ bool sphere_t(V3 o, V3 d, float tmin, float tmax, V3 
     if (disc < 0.0f) return false;
     float sq = __builtin_amdgcn_sqrtf(disc);
     float q = -(hb + __builtin_copysignf(sq, hb));
-    float r0 = q / a, r1 = cc / q;
+    float r0 = q * __builtin_amdgcn_rcpf(a), r1 = cc * __builtin_amdgcn_rcpf(q);
     float t_near = fminf(r0, r1), t_far = fmaxf(r0, r1);
     float cand = (t_near > tmin && t_near < tmax) ? t_near : t_far;
     if (!(cand > tmin && cand < tmax)) return false;
@@ -85,7 +88,7 @@ __device__ __forceinline__ bool sphere_t(V3 o, V3 d, float tmin, float tmax, V3 
 // PlaneObject::hit, inc/RTObjects.h:174-177
 __device__ __forceinline__ bool plane_t(V3 o, V3 d, float tmin, float tmax, const DPrim &pr, float &t) {
     V3 pos = mk(pr.p[0], pr.p[1], pr.p[2]), n = mk(pr.p[3], pr.p[4], pr.p[5]);
-    float time = dot(n, pos - o) * (1.0f / dot(n, d));
+    float time = dot(n, pos - o) * __builtin_amdgcn_rcpf(dot(n, d));
     if (!(time > tmin && time < tmax)) return false;
     t = time;
     return true;
@@ -105,7 +108,7 @@ __device__ __forceinline__ bool box_t(V3 o, V3 d, float tmin_i, float tmax_i, V3
         if (fabsf(dir[i]) < 1e-12f) {
             if (orig[i] < lo || orig[i] > hi) return false;
         } else {
-            float inv = 1.0f / dir[i];
+            float inv = __builtin_amdgcn_rcpf(dir[i]);
             float t0 = (lo - orig[i]) * inv, t1 = (hi - orig[i]) * inv;
             int f0 = 2 * i, f1 = 2 * i + 1;
             if (t0 > t1) {
@@ -139,7 +142,7 @@ __device__ __forceinline__ bool polygon_t(V3 o, V3 d, float tmin, float tmax, co
     V3 n = mk(pr.p[0], pr.p[1], pr.p[2]), cen = mk(pr.p[3], pr.p[4], pr.p[5]);
     float denom = dot(n, d);
     if (fabsf(denom) < 1e-12f) return false;
-    float time = dot(n, cen - o) / denom;
+    float time = dot(n, cen - o) * __builtin_amdgcn_rcpf(denom);
     if (!(time > tmin && time < tmax)) return false;
     V3 p = madd(o, d, time);
     float px, py;
@@ -154,7 +157,7 @@ __device__ __forceinline__ bool polygon_t(V3 o, V3 d, float tmin, float tmax, co
         float xi, yi, xj, yj;
         project2d(n, vi, xi, yi);
         project2d(n, vj, xj, yj);
-        bool cross = ((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi + 1e-20f) + xi);
+        bool cross = ((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) * __builtin_amdgcn_rcpf(yj - yi + 1e-20f) + xi);
         inside = inside != cross;
         vj = vi;
     }
