@@ -534,7 +534,9 @@ __device__ __forceinline__ V3 light_direct(const DLight lt, V3 cam_center, V3 p,
         V3 refl = madd(to_light * -1.0f, n, 2.0f * cos_l);
         float cos_v = dot(normalized(refl), to_view);
         if (cos_v > 0.0f) {
-            float k = powf(cos_v, lt.pos_pow.w);
+            // cos_v is in (0, 1]: exp2(pow * log2(cos_v)) with the hardware's v_log_f32 / v_exp_f32 (relative error about
+            // 2e-7 * pow) instead of the library's correctly rounded power, thirty instructions per shadow query
+            float k = __builtin_amdgcn_exp2f(lt.pos_pow.w * __builtin_amdgcn_logf(cos_v));
             out = out + mk(k, k, k);
         }
     }
