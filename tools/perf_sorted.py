@@ -13,11 +13,14 @@ def morton(x, y, bits=10):
         return r
     return spread(x) | (spread(y) << 1)
 
-base = scenes.by_name("random_spheres")
+name0 = sys.argv[1] if len(sys.argv) > 1 else "random_spheres"
+base = scenes.by_name(name0)
+W, H, SPP = (1200, 675, 200) if name0 == "random_spheres" else (960, 540, 16)
 sp = base.spheres
 order = list(range(len(sp)))
-xs = ((sp["cx"] + 12) / 24 * 1023).astype(int).clip(0, 1023)
-ys = ((sp["cy"] + 12) / 24 * 1023).astype(int).clip(0, 1023)
+ext = float(max(np.abs(sp["cx"][1:]).max(), np.abs(sp["cy"][1:]).max())) + 1.0
+xs = ((sp["cx"] + ext) / (2 * ext) * 1023).astype(int).clip(0, 1023)
+ys = ((sp["cy"] + ext) / (2 * ext) * 1023).astype(int).clip(0, 1023)
 keys = [morton(int(xs[i]), int(ys[i])) for i in order]
 sorted_order = [0] + sorted(order[1:], key=lambda i: keys[i])
 for name, od in (("as built", order), ("morton", sorted_order), ("as built", order), ("morton", sorted_order)):
@@ -29,6 +32,6 @@ for name, od in (("as built", order), ("morton", sorted_order), ("as built", ord
     sc = b.build("rs", base.camera)
     with Renderer(0) as r:
         r.set_scene(sc)
-        p = RenderParams(1200, 675, 200, 50)
+        p = RenderParams(W, H, SPP, 50)
         r.render_host(p); _, _, rays = r.render_host(p)
         print(f"{name}: {r.last_kernel_ms():.2f} ms, rays {rays}")
