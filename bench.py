@@ -157,7 +157,7 @@ class Job:
             # arithmetic is the dense f16 MFMA peak, priced at the products the kernel really issues for the
             # rays it traced.  The algorithmic rate of the reference's fp32 formulation is given beside it, with
             # the FP32 vector peak that bounded the packed-FP32 form of the same filter.
-            mfma = rays_per_launch * FLOP_PER_ROW_MFMA * info["n_rows"] / (kern_ms * 1e-3) / 1e12
+            mfma = rays_per_launch * FLOP_PER_ROW_MFMA * (info.get("table_rows") or info["n_rows"]) / (kern_ms * 1e-3) / 1e12
             return {
                 "bound": "mfma",
                 "achieved": round(mfma, 3),
@@ -176,7 +176,7 @@ class Job:
                 "traffic_source": traffic_src,
                 "kernel": "render_kernel",
                 "kernel_ms": round(kern_ms, 3),
-                "flop_model": f"matrix: rays*{FLOP_PER_ROW_MFMA}*{info['n_rows']} table rows; algorithmic: "
+                "flop_model": f"matrix: rays*{FLOP_PER_ROW_MFMA}*{(info.get('table_rows') or info['n_rows'])} table rows; algorithmic: "
                               f"rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}); rays/launch={rays_per_launch:.0f}",
             }
         return {

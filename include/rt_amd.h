@@ -326,13 +326,15 @@ typedef struct rt_filter_info {
     float radius;       /* its unit length: the radius of the sphere cloud */
     float margin;       /* a sphere passes when disc / radius^2 + margin + margin_far * max|O'_i| > 0 */
     float margin_far;   /*   (disc: discriminant of the unit-direction quadratic; O': origin in frame units) */
-    int32_t n_rows;     /* rows of the filter table (row = sphere index; padded to a multiple of 32) */
+    int32_t n_rows;     /* columns of rt_filter_values_host: one per sphere index, padded to a multiple of 32 */
     int32_t n_big;      /* spheres decided outside the filter ... */
-    int32_t big[8];     /* ... and their indices; their rows never pass */
+    int32_t big[8];     /* ... and their indices; their columns never pass */
+    int32_t n_table_rows; /* rows of the table the kernel multiplies (the other spheres along a space-filling
+                           * curve, padded to blocks of 32 and, when streamed through LDS, to tiles of 16 blocks) */
 } rt_filter_info;
 int rt_filter_describe(rt_ctx *ctx, rt_filter_info *out);
-/* Filter values of n rays (origin, direction: 3 floats each, direction of any length) against every row,
- * computed by the device code the render kernel runs: values[ray * n_rows + row], in frame units with
+/* Filter values of n rays (origin, direction: 3 floats each, direction of any length) against every sphere,
+ * computed by the device code the render kernel runs: values[ray * n_rows + sphere index], in frame units with
  * the sign convention of the kernel (NEGATIVE = the sphere passes), i.e. an approximation of
  * -(disc / radius^2 + margin + margin_far * max|O'_i|).  Host pointers, synchronous. */
 int rt_filter_values_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir, float *h_values);

@@ -93,7 +93,8 @@ EXPORTS = [
 
 class _FilterInfo(C.Structure):
     _fields_ = [("in_use", C.c_int32), ("center", C.c_float * 3), ("radius", C.c_float), ("margin", C.c_float),
-                ("margin_far", C.c_float), ("n_rows", C.c_int32), ("n_big", C.c_int32), ("big", C.c_int32 * 8)]
+                ("margin_far", C.c_float), ("n_rows", C.c_int32), ("n_big", C.c_int32), ("big", C.c_int32 * 8),
+                ("n_table_rows", C.c_int32)]
 
 
 _lib = None
@@ -334,7 +335,7 @@ class Renderer:
         self._check(self.lib.rt_filter_describe(self.h, C.byref(fi)), "rt_filter_describe")
         return {"in_use": bool(fi.in_use), "center": np.array(list(fi.center), dtype=np.float32), "radius": float(fi.radius),
                 "margin": float(fi.margin), "margin_far": float(fi.margin_far), "n_rows": int(fi.n_rows),
-                "big": [int(fi.big[i]) for i in range(fi.n_big)]}
+                "big": [int(fi.big[i]) for i in range(fi.n_big)], "table_rows": int(fi.n_table_rows)}
 
     def filter_values(self, org: np.ndarray, dir: np.ndarray) -> np.ndarray:
         """Device-evaluated filter values [n_rays, n_rows]; negative = the sphere of that row passes."""

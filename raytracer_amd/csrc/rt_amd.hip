@@ -158,6 +158,8 @@ struct DeviceScene {
     const DMat *mats;
     const DLight *lights;
     const uint4v *mf_table; // matrix-core filter table, MF_BLOCK_WORDS 16-byte words per 32 spheres
+    const float4 *mf_rows;  // the sphere (cx, cy, cz, r) behind every table row ...
+    const int *mf_row_idx;  // ... and its index in `sph` (rows are in the order of a space-filling curve)
     FullScene full; // general primitive list (used by the FULL kernel variants only)
 };
 
@@ -378,6 +380,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
     CandQ cq;
     cq.slot = reinterpret_cast<unsigned long long *>(smem + acc_bytes_of(SRC, FULL)) + wave * 64;
     cq.ent = reinterpret_cast<unsigned *>(smem + acc_bytes_of(SRC, FULL) + NW * 64 * sizeof(unsigned long long)) + wave * cand_cap_of(SRC);
+    cq.row_idx = is_mfma(SRC) ? KS.mf_row_idx : nullptr;
 
     const int nquads = KP.n_quads; // groups of four spheres, padding included
     if (SRC == SRC_LDS_RESIDENT) {
@@ -473,10 +476,10 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
         } else if constexpr (SRC == SRC_LDS_RESIDENT) {
             if (active) scan_lds(lds_sph, lds_r2, nquads, 0, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
         } else if constexpr (SRC == SRC_MFMA) {
-            scan_mfma(lds_tab, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph, best_t, best_id, sec);
+            scan_mfma(lds_tab, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph, KS.mf_rows, best_t, best_id, sec);
         } else if constexpr (SRC == SRC_MFMA_STREAMED) {
             scan_mfma_streamed<WGT>(lds_tab, KS.mf_table, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph,
-                                    best_t, best_id, sec);
+                                    KS.mf_rows, best_t, best_id, sec);
         } else {
             // the whole wave scans: a lane without a ray passes no filter
             rk.thr = active ? rk.thr : __builtin_inff();
@@ -796,7 +799,8 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
 // kernel's scan (test hook).  One wave per 64 rays; the table words come from global memory here.
 __global__ __launch_bounds__(64) void filter_probe_kernel(int n_rays, const float *__restrict__ org,
                                                           const float *__restrict__ dir, const uint4v *__restrict__ tab,
-                                                          MfmaFrame fr, float *__restrict__ out) {
+                                                          const int *__restrict__ row_idx, int n_cols, MfmaFrame fr,
+                                                          float *__restrict__ out) {
     const int lane = threadIdx.x, base = blockIdx.x * 64, i = base + lane;
     const bool live = i < n_rays;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
@@ -806,7 +810,6 @@ __global__ __launch_bounds__(64) void filter_probe_kernel(int n_rays, const floa
     }
     const V3 dh = d * __frsqrt_rn(dot(d, d)); // as set_dir() does
     const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
-    const int n_rows = fr.n_blocks * MF_BLOCK;
     for (int blk = 0; blk < fr.n_blocks; ++blk) {
         const half8 a0 = __builtin_bit_cast(half8, tab[(2 * blk) * 64 + lane]);
         const half8 a1 = __builtin_bit_cast(half8, tab[(2 * blk + 1) * 64 + lane]);
@@ -814,10 +817,11 @@ __global__ __launch_bounds__(64) void filter_probe_kernel(int n_rays, const floa
         const float16v acc1 = mfma_tile(a0, a1, op.b[1][0], op.b[1][1]);
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int row = MF_BLOCK * blk + v + 16 * (lane >> 5); // the sphere behind register v (rt_mfma.h)
+            const int row = MF_BLOCK * blk + v + 16 * (lane >> 5); // the table row behind register v (rt_mfma.h)
+            const int col = row_idx[row];                          // the sphere it holds; -1: padding
             const int r0 = base + (lane & 31), r1 = r0 + 32;
-            if (r0 < n_rays) out[(size_t)r0 * n_rows + row] = acc0[v] * (1.0f / (MF_SCALE * MF_SCALE));
-            if (r1 < n_rays) out[(size_t)r1 * n_rows + row] = acc1[v] * (1.0f / (MF_SCALE * MF_SCALE));
+            if (col >= 0 && r0 < n_rays) out[(size_t)r0 * n_cols + col] = acc0[v] * (1.0f / (MF_SCALE * MF_SCALE));
+            if (col >= 0 && r1 < n_rays) out[(size_t)r1 * n_cols + col] = acc1[v] * (1.0f / (MF_SCALE * MF_SCALE));
         }
     }
 }
@@ -1187,11 +1191,12 @@ __global__ __launch_bounds__(WG_THREADS) void first_hit_mfma_kernel(int n_rays, 
     CandQ cq;
     cq.slot = slots + wave * 64;
     cq.ent = ents + wave * cand_cap_of(SRC_MFMA);
+    cq.row_idx = sc.mf_row_idx;
     float best_t = __builtin_inff(); // in units of |d| during the scan
     int best_id = -1;
     SecClock sec;
     sec.start();
-    scan_mfma(sc.mf_table, fr, o, dh, live, tmin * len, -1, lane, cq, sc.sph, best_t, best_id, sec);
+    scan_mfma(sc.mf_table, fr, o, dh, live, tmin * len, -1, lane, cq, sc.sph, sc.mf_rows, best_t, best_id, sec);
     if (!live) return;
     best_t *= inv_len;
     if (expanded) expanded[i] = 0;
@@ -1295,6 +1300,9 @@ struct rt_ctx {
     bool scalar_source = true;
     // matrix-core filter table (rt_mfma.h): built with every scene it can serve
     uint4v *d_mf_table = nullptr;
+    float4 *d_mf_rows = nullptr;
+    int *d_mf_row_idx = nullptr;
+    int mf_cols = 0; // columns of rt_filter_values_host: one per sphere index, padded
     MfmaFrame mf{};
     bool mf_usable = false;  // the scene has a table and it fits in LDS
     bool mf_wanted = true;   // RT_AMD_SPHERE_SOURCE did not ask for another source
@@ -1464,7 +1472,8 @@ RT_API int rt_filter_describe(rt_ctx *ctx, rt_filter_info *out) {
     out->radius = MF_SCALE / ctx->mf.scale;
     out->margin = MF_MARGIN;
     out->margin_far = MF_MARGIN_FAR;
-    out->n_rows = ctx->mf.n_blocks * MF_BLOCK;
+    out->n_rows = ctx->mf_cols;
+    out->n_table_rows = ctx->mf.n_blocks * MF_BLOCK;
     out->n_big = ctx->mf.n_big;
     for (int i = 0; i < ctx->mf.n_big; ++i) out->big[i] = ctx->mf.big[i];
     return RT_OK;
@@ -1477,15 +1486,17 @@ RT_API int rt_filter_values_host(rt_ctx *ctx, int n_rays, const float *h_org, co
     if (n_rays < 0 || (n_rays > 0 && (!h_org || !h_dir || !h_values))) return fail(ctx, RT_ERR_INVALID, "bad ray / value array");
     if (n_rays == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t rb = (size_t)n_rays * 12, vb = (size_t)n_rays * (size_t)ctx->mf.n_blocks * MF_BLOCK * 4;
+    const size_t rb = (size_t)n_rays * 12, vb = (size_t)n_rays * (size_t)ctx->mf_cols * 4;
     HIP_TRY(ctx, reserve(ctx, &ctx->fh_org, rb));
     HIP_TRY(ctx, reserve(ctx, &ctx->fh_dir, rb));
     HIP_TRY(ctx, reserve(ctx, &ctx->fh_nrm, vb));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->fh_org, h_org, rb, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->fh_dir, h_dir, rb, hipMemcpyHostToDevice, ctx->stream));
+    // columns of spheres that have no row (decided outside the table) and the padding read +1: they never pass
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->fh_nrm, 0x3f800000, vb / 4, ctx->stream));
     hipLaunchKernelGGL(filter_probe_kernel, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, ctx->stream, n_rays,
-                       (const float *)ctx->fh_org, (const float *)ctx->fh_dir, (const uint4v *)ctx->d_mf_table, ctx->mf,
-                       (float *)ctx->fh_nrm);
+                       (const float *)ctx->fh_org, (const float *)ctx->fh_dir, (const uint4v *)ctx->d_mf_table,
+                       (const int *)ctx->d_mf_row_idx, ctx->mf_cols, ctx->mf, (float *)ctx->fh_nrm);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(h_values, ctx->fh_nrm, vb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1586,6 +1597,8 @@ DeviceScene device_scene(const rt_ctx *ctx) {
     sc.sph_mats = ctx->d_sph_mats;
     sc.lights = ctx->d_lights;
     sc.mf_table = ctx->d_mf_table;
+    sc.mf_rows = ctx->d_mf_rows;
+    sc.mf_row_idx = ctx->d_mf_row_idx;
     sc.full.prims = as_const(ctx->d_prims);
     sc.full.verts = as_const(ctx->d_verts);
     sc.full.others = as_const(ctx->d_others);
@@ -1635,6 +1648,8 @@ double half_value(uint16_t h) {
 // the lane layout of the 32x32x16 A operand.  `ok` is false when the scene cannot use it.
 struct MfTable {
     std::vector<uint32_t> words;
+    std::vector<float4> rows;    // the sphere of every table row (padding: zeros) ...
+    std::vector<int32_t> row_idx; // ... and its index in the scene's sphere list (padding: -1)
     MfmaFrame fr;
     bool ok = false;
 };
@@ -1700,7 +1715,33 @@ MfTable build_mf_table(const std::vector<float4> &sph) {
     // the kernel computes O' = (O - c0) * scale in float: the table follows those floats exactly
     const float c0f[3] = {(float)c0[0], (float)c0[1], (float)c0[2]};
     const double inv_rs = (double)scale / (double)MF_SCALE;
-    int n_blocks = (n + MF_BLOCK - 1) / MF_BLOCK;
+    // Rows: the spheres of the table along a Morton curve through the cloud (10 bits per axis of the frame's cube),
+    // ties and equal cells in scene order, so that a block of 32 rows is a compact patch.
+    std::vector<int32_t> order;
+    order.reserve((size_t)n);
+    for (int i = 0; i < n; ++i)
+        if (!big[i]) order.push_back(i);
+    {
+        auto spread = [](uint32_t v) { // 10 bits -> every third bit
+            uint64_t r = 0;
+            for (int b = 0; b < 10; ++b) r |= (uint64_t)((v >> b) & 1u) << (3 * b);
+            return r;
+        };
+        std::vector<uint64_t> key((size_t)n, 0);
+        for (int i : order) {
+            uint64_t k = 0;
+            const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
+            for (int a = 0; a < 3; ++a) {
+                double u = ((cc[a] - c0[a]) / Rs + 1.0) * 0.5; // the cloud lies in [-1, 1]^3 of the frame
+                u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+                k |= spread((uint32_t)(u * 1023.0)) << a;
+            }
+            key[i] = k;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    }
+    const int n_table = (int)order.size();
+    int n_blocks = (n_table + MF_BLOCK - 1) / MF_BLOCK;
     // a table that does not fit in LDS is streamed through it in whole tiles
     if (mf_lds_resident(n_blocks) > MF_LDS_BYTES) n_blocks = (n_blocks + MF_TILE_BLOCKS - 1) / MF_TILE_BLOCKS * MF_TILE_BLOCKS;
     T.fr.cx = c0f[0]; T.fr.cy = c0f[1]; T.fr.cz = c0f[2];
@@ -1708,13 +1749,19 @@ MfTable build_mf_table(const std::vector<float4> &sph) {
     T.fr.n_blocks = n_blocks;
     T.fr.n_big = n_big;
     // one spare block of rows that never pass follows the list: the scan reads one block ahead
-    T.words.assign((size_t)(n_blocks + 1) * MF_BLOCK_WORDS * 4, 0u);
-    for (int row = 0; row < (n_blocks + 1) * MF_BLOCK; ++row) {
+    const int n_rows = (n_blocks + 1) * MF_BLOCK;
+    T.words.assign((size_t)n_rows * MF_BLOCK_WORDS / MF_BLOCK * 4, 0u);
+    T.rows.assign((size_t)n_rows, make_float4(0, 0, 0, 0));
+    T.row_idx.assign((size_t)n_rows, -1);
+    for (int row = 0; row < n_rows; ++row) {
         uint16_t hi[9] = {0}, lo[9] = {0}, q_hi = half_rn(MF_NEVER), q_lo = 0;
         const uint16_t unit = half_rn(-MF_SCALE);
-        if (row < n && !big[row]) {
-            const double x = ((double)sph[row].x - c0f[0]) * inv_rs, y = ((double)sph[row].y - c0f[1]) * inv_rs,
-                         z = ((double)sph[row].z - c0f[2]) * inv_rs, r = (double)sph[row].w * inv_rs;
+        if (row < n_table) {
+            const int si = order[(size_t)row];
+            T.rows[(size_t)row] = sph[si];
+            T.row_idx[(size_t)row] = si;
+            const double x = ((double)sph[si].x - c0f[0]) * inv_rs, y = ((double)sph[si].y - c0f[1]) * inv_rs,
+                         z = ((double)sph[si].z - c0f[2]) * inv_rs, r = (double)sph[si].w * inv_rs;
             const double feat[9] = {x * x, y * y, z * z, 2 * x * y, 2 * x * z, 2 * y * z, 2 * x, 2 * y, 2 * z};
             for (int f = 0; f < 9; ++f) {
                 const double S = -(double)MF_SCALE * feat[f];
@@ -1843,6 +1890,10 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
     if (mft.ok) {
         HIP_TRY(ctx, reserve(ctx, (void **)&ctx->d_mf_table, mft.words.size() * 4));
         HIP_TRY(ctx, hipMemcpy(ctx->d_mf_table, mft.words.data(), mft.words.size() * 4, hipMemcpyHostToDevice));
+        if ((rc = to_device(ctx, &ctx->d_mf_rows, mft.rows)) != RT_OK) return rc;
+        if ((rc = to_device(ctx, &ctx->d_mf_row_idx, mft.row_idx)) != RT_OK) return rc;
+        const int padded = ((int)sph.size() + MF_BLOCK - 1) / MF_BLOCK * MF_BLOCK;
+        ctx->mf_cols = std::max(mft.fr.n_blocks * MF_BLOCK, padded);
         ctx->mf = mft.fr;
         // how many workgroups of the variant this table takes stay resident on a CU: asked once per scene, so a
         // render issues nothing but its counter reset and its launch

@@ -336,6 +336,9 @@ constexpr unsigned long long NO_HIT_KEY = ~0ull;
 struct CandQ {
     unsigned *ent;            // CAND_CAP entries: lane | sphere << 6
     unsigned long long *slot; // per lane of the wave: the closest hit so far, NO_HIT_KEY = none
+    // the matrix-core filter numbers its candidates by table row: row -> sphere index (null: the entry holds
+    // the sphere index itself, and the array handed to resolve_batch() is the scene's sphere list)
+    const int *row_idx;
 };
 
 __device__ __forceinline__ int lane_rank(unsigned long long m) {
@@ -368,8 +371,9 @@ __device__ __forceinline__ void resolve_batch(const CandQ &cq, int &count, int n
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const unsigned e = cq.ent[head + min(lane, n - 1)];
     const int src = (int)(e & 63u) << 2;
-    const int s = (int)(e >> 6);
-    const float4 sp = sph[s];
+    const int row = (int)(e >> 6);
+    const float4 sp = sph[row];
+    const int s = cq.row_idx ? cq.row_idx[row] : row;
     const V3 ro = mk(lane_fetch(src, o.x), lane_fetch(src, o.y), lane_fetch(src, o.z));
     const V3 rd = mk(lane_fetch(src, dh.x), lane_fetch(src, dh.y), lane_fetch(src, dh.z));
     const float rt = lane_fetch(src, tmin);
