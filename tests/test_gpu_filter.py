@@ -323,15 +323,19 @@ def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatc
     radiance sums and ray counts are equal."""
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([16, 17, 31, 33, 64, 200, 485, 1000, 1472, 1473, 2000, 3000]))
-    box = (float(rng.uniform(3, 30)), float(rng.uniform(3, 30)), float(rng.uniform(0.5, 8)))
     rmax = float(rng.uniform(0.1, 1.0))
+    # a box the spheres fill well enough for paths to bounce: about six largest-sphere areas of floor per sphere
+    side, stretch = float(np.sqrt(n * 6.0) * rmax), float(rng.uniform(0.5, 2.0))
+    box = (0.5 * side * stretch, 0.5 * side / stretch, rmax * float(rng.uniform(1.0, 6.0)))
     extra = [((float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5)), -float(rng.uniform(200, 2000))), None)
              for _ in range(int(rng.integers(0, 4)))]
     extra = [(c, -c[2] - box[2]) for c, _ in extra]  # large spheres whose tops lie just under the cloud
-    scene = _cloud(f"rand{seed}", n, 2000 + seed, box=box, radii=(rmax / float(rng.uniform(3, 100)), rmax), extra=extra)
+    scene = _cloud(f"rand{seed}", n, 2000 + seed, box=box, radii=(rmax / float(rng.uniform(1.5, 30)), rmax), extra=extra)
     if rng.random() < 0.4:  # the camera inside the cloud
         c = np.array([0.0, 0.0, 0.2 * box[2]])
-        scene.camera = scenes.make_camera(c, rng.normal(size=3))
+        dvec = rng.normal(size=3)
+        dvec[2] = -abs(dvec[2]) * 0.3 - 0.05  # along the cloud, slightly downwards
+        scene.camera = scenes.make_camera(c, dvec)
     p = RenderParams(80, 48, int(rng.choice([4, 16, 40])), int(rng.choice([3, 12, 50])), seed=seed)
     with Renderer(0) as r:
         r.set_scene(scene)
@@ -343,3 +347,6 @@ def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatc
         b = r.render_host(p, want_accum=True)
     assert a[2] == b[2], f"n={n}: ray counts differ: {a[2]} vs {b[2]}"
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), f"n={n}"
+    # the scene is in view: paths bounce, and the frame is not one colour
+    assert a[2] > 1.003 * p.width * p.height * p.samples_per_pixel, (n, a[2])
+    assert len(np.unique(a[0][:, :, :3].reshape(-1, 3), axis=0)) > 50, n

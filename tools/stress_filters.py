@@ -1,0 +1,28 @@
+"""Tuning / confidence aid: many random sphere clouds rendered with the matrix-core filter and with the packed filter;
+frames, sums and ray counts must be equal (the scenes of tests/test_gpu_filter.py's random-cloud test, more seeds).
+usage: stress_filters.py [first_seed last_seed]"""
+import os
+import sys
+import time
+sys.path.insert(0, '.')
+import importlib.util
+spec = importlib.util.spec_from_file_location('tf', 'tests/test_gpu_filter.py')
+tf = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(tf)
+
+
+class Env:
+    def setenv(self, k, v):
+        os.environ[k] = v
+
+
+first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100, 400)
+bad, t0 = 0, time.time()
+for seed in range(first, last):
+    os.environ.pop("RT_AMD_SPHERE_SOURCE", None)
+    try:
+        tf.test_random_clouds_render_the_same_bytes_with_either_filter(seed, Env())
+    except AssertionError as e:
+        bad += 1
+        print("seed", seed, "FAILED", str(e)[:200])
+print(f"{last - first} scenes in {time.time() - t0:.1f} s, failures: {bad}")
