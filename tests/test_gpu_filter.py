@@ -317,7 +317,7 @@ def test_single_ray_queries_through_the_table(oracle64):
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
-def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatch):
+def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatch, lit=False):
     """Random scenes (16 to 3000 spheres, radii over two decades, up to three very large spheres, the camera
     inside or outside the cloud): the matrix-core filter and the packed filter select the same hits, so frames,
     radiance sums and ray counts are equal."""
@@ -337,6 +337,16 @@ def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatc
         dvec[2] = -abs(dvec[2]) * 0.3 - 0.05  # along the cloud, slightly downwards
         scene.camera = scenes.make_camera(c, dvec)
     p = RenderParams(80, 48, int(rng.choice([4, 16, 40])), int(rng.choice([3, 12, 50])), seed=seed)
+    if lit:  # tools/stress_filters.py: the general kernel, with a light above the cloud
+        from raytracer_amd.api import FLAG_DIRECT_LIGHT, LIGHT_DTYPE
+        lights = np.zeros(1, dtype=LIGHT_DTYPE)
+        lights[0]["position"] = (0.3 * box[0], -0.2 * box[1], 3.0 * box[2] + 2.0)
+        lights[0]["ambient"] = (0.03, 0.03, 0.03)
+        lights[0]["diffuse"] = (0.5, 0.5, 0.45)
+        lights[0]["specular"] = (0.8, 0.8, 0.8)
+        lights[0]["view_pow"] = 16.0
+        scene.lights = lights
+        p.flags = FLAG_DIRECT_LIGHT
     with Renderer(0) as r:
         r.set_scene(scene)
         assert r.filter_describe()["in_use"]

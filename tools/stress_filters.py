@@ -1,6 +1,6 @@
 """Tuning / confidence aid: many random sphere clouds rendered with the matrix-core filter and with the packed filter;
 frames, sums and ray counts must be equal (the scenes of tests/test_gpu_filter.py's random-cloud test, more seeds).
-usage: stress_filters.py [first_seed last_seed]"""
+usage: [LIT=1] stress_filters.py [first_seed last_seed]      (LIT=1: with a light, i.e. through the general kernel)"""
 import os
 import sys
 import time
@@ -21,7 +21,7 @@ bad, t0 = 0, time.time()
 for seed in range(first, last):
     os.environ.pop("RT_AMD_SPHERE_SOURCE", None)
     try:
-        tf.test_random_clouds_render_the_same_bytes_with_either_filter(seed, Env())
+        tf.test_random_clouds_render_the_same_bytes_with_either_filter(seed, Env(), lit=os.environ.get("LIT") == "1")
     except AssertionError as e:
         bad += 1
         print("seed", seed, "FAILED", str(e)[:200])
