@@ -288,6 +288,7 @@ __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *_
     // the previous scan's readers of buffer 0 are done: every wave has passed the last barrier of that scan
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) bufs[tid + k * WG_THREADS_T] = gtab[tid + k * WG_THREADS_T];
+    sec.mark(12); // tuning build: 12 = first tile and its barrier, 13 = the barriers between tiles
     __syncthreads();
     sec.mark(8);
     for (int t = 0; t < n_tiles; ++t) {
@@ -303,7 +304,9 @@ __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *_
 #pragma unroll
             for (int k = 0; k < PER_THREAD; ++k) dst[tid + k * WG_THREADS_T] = next[k];
         }
+        sec.mark(13);
         __syncthreads(); // the next tile is complete, and nobody still reads the buffer after it
+        sec.mark(8);
     }
     mfma_scan_finish(fr, cq, count, lane, o, dh, live, tmin, self_id, sph, rows, best_t, best_id, sec);
 }

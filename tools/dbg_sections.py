@@ -20,7 +20,7 @@ lib.rt_debug_sections(out, 0)
 v = list(out); tot = sum(v)
 names = ["ray set-up + scan", "shade", "accumulate", "store tiles", "hand-out", "rng + raygen/scatter", "-", "outside loop",
          "scan: matrix products + sign masks", "scan: recording candidates", "scan: deciding candidates",
-         "scan: big spheres + result", "-", "-", "-", "-"]
+         "scan: big spheres + result", "streamed: first tile + barrier", "streamed: tile barriers", "-", "-"]
 print(f"{name} {W}x{H} {spp} spp: kernel {r.last_kernel_ms():.2f} ms, rays {rays}")
 for n, x in zip(names, v):
     if x: print(f"  {n:24s} {100.0 * x / tot:6.2f} % of wave cycles")
