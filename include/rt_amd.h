@@ -225,6 +225,13 @@ int rt_render_host(rt_ctx *ctx, const rt_params *p, uint8_t *h_rgba, float *h_ac
 float rt_last_kernel_ms(const rt_ctx *ctx);
 uint64_t rt_device_allocations(const rt_ctx *ctx);
 
+/* Which form of the render kernel the context's last render launched (-1: none yet): where its sphere scan takes
+ * the spheres from -- 0 their LDS-resident copy, 1 tiles streamed through LDS, 2 scalar loads (the packed FP32
+ * filter), 3 the matrix-core filter with its table resident in LDS, 4 the same with the table streamed through
+ * LDS -- plus 8 when it was the general kernel (lights, other primitive kinds, the selection halo).  Replaces
+ * nothing in the reference; for tests and tuning. */
+int rt_last_kernel_variant(const rt_ctx *ctx);
+
 /* First-hit flags */
 enum {
     RT_FH_REFINE = 1u << 0,  /* re-test numerically ambiguous rays in fp64 so that the

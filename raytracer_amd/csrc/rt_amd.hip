@@ -73,7 +73,8 @@ constexpr size_t MF_LDS_BYTES = 159 * 1024; // dynamic LDS a workgroup of the ma
 #define RT_MF_FULL_THREADS 768
 #endif
 constexpr int wg_threads_of(int src, bool full = false) {
-    return src == SRC_MFMA ? (full ? RT_MF_FULL_THREADS : 1024) : src == SRC_MFMA_STREAMED ? RT_MF_STREAM_THREADS : WG_THREADS;
+    return src == SRC_MFMA ? (full ? RT_MF_FULL_THREADS : 1024)
+           : src == SRC_MFMA_STREAMED ? (full ? RT_MF_FULL_THREADS : RT_MF_STREAM_THREADS) : WG_THREADS;
 }
 constexpr int cand_cap_of(int src) { return is_mfma(src) ? 128 : CAND_CAP; }
 constexpr size_t acc_bytes_of(int src, bool full = false) {
@@ -1310,6 +1311,9 @@ struct rt_ctx {
     int mf_resident = 0;     // workgroups of the scene's matrix-core variant a CU holds (queried at upload)
     int mf_full_min = 24; // sphere count from which the general kernel takes the table (measured: even at 16, 5 % ahead at 32, 26 % at 64; tuning: RT_AMD_MF_FULL_MIN)
     int mf_resident_full = 0; // the same for the general kernel's variant (0: its table does not fit, or no such device)
+    bool mf_full_streamed_ok = true;
+    int last_variant = -1; // sphere source of the last render launch, + 8 for the general kernel
+    int mf_streamed_full = 0; // the same for the general kernel's variant with the table streamed through LDS
     unsigned char *d_queue = nullptr; // ring of work-item counters of the persistent render kernel
     unsigned queue_next = 0;          // next slot of the ring
     unsigned char *d_scratch = nullptr; // this device's copy of `scratch` (rt_render_noalloc)
@@ -1436,7 +1440,7 @@ extern "C" __attribute__((visibility("default"))) int rt_debug_stats(unsigned lo
 }
 #endif
 
-RT_API int rt_version(void) { return 102; }
+RT_API int rt_version(void) { return 103; }
 
 RT_API void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint32_t out[4]) {
     rng4(pixel, sample, call, seed, out[0], out[1], out[2], out[3]);
@@ -1549,6 +1553,11 @@ RT_API int rt_create(int device, rt_ctx **out) {
         (void)hipGetLastError();
         ctx->mf_wanted = false;
     }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<SRC_MFMA_STREAMED, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)MF_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->mf_full_streamed_ok = false;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cus = prop.multiProcessorCount;
@@ -1658,8 +1667,15 @@ struct MfTable {
 size_t mf_lds_resident(int n_blocks, bool full = false) {
     return wave_state_bytes_of(SRC_MFMA, full) + (size_t)(n_blocks + 1) * MF_BLOCK_WORDS * 16;
 }
-constexpr size_t MF_LDS_STREAMED = wave_state_bytes_of(SRC_MFMA_STREAMED) + 2 * (size_t)MF_TILE_WORDS * 16;
-static_assert(MF_LDS_STREAMED <= MF_LDS_BYTES, "two tiles and the wave state fit in LDS");
+constexpr size_t mf_lds_streamed(bool full = false) {
+    return wave_state_bytes_of(SRC_MFMA_STREAMED, full) + 2 * (size_t)MF_TILE_WORDS * 16;
+}
+static_assert(mf_lds_streamed(false) <= MF_LDS_BYTES && mf_lds_streamed(true) <= MF_LDS_BYTES,
+              "two tiles and the wave state fit in LDS");
+// a table is padded to whole tiles when the sphere-only kernel cannot keep it resident; the general kernel, whose
+// workgroup is smaller, then streams it too or holds all of it
+static_assert(wave_state_bytes_of(SRC_MFMA, true) <= wave_state_bytes_of(SRC_MFMA, false),
+              "whatever the general kernel must stream is padded to whole tiles");
 
 MfTable build_mf_table(const std::vector<float4> &sph) {
     MfTable T;
@@ -1904,11 +1920,11 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
                 fits ? reinterpret_cast<const void *>(&render_kernel<SRC_MFMA, false>)
                      : reinterpret_cast<const void *>(&render_kernel<SRC_MFMA_STREAMED, false>),
                 wg_threads_of(fits ? SRC_MFMA : SRC_MFMA_STREAMED),
-                fits ? mf_lds_resident(mft.fr.n_blocks) : MF_LDS_STREAMED) != hipSuccess)
+                fits ? mf_lds_resident(mft.fr.n_blocks) : mf_lds_streamed()) != hipSuccess)
             resident = 0;
         (void)hipGetLastError();
         ctx->mf_resident = resident;
-        // the general kernel takes the table only when it stays resident in LDS beside the larger path state
+        // the general kernel keeps the table resident in LDS beside its larger path state when it fits ...
         int resident_full = 0;
         if (ctx->mf_full_ok && mf_lds_resident(mft.fr.n_blocks, true) <= MF_LDS_BYTES &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_full,
@@ -1918,6 +1934,15 @@ int upload_prims(rt_ctx *ctx, int n_prims, const rt_prim *h_prims, int n_vertice
             resident_full = 0;
         (void)hipGetLastError();
         ctx->mf_resident_full = resident_full;
+        // ... and streams a table that does not (the sphere-only kernel's does not fit either then: whole tiles)
+        int streamed_full = 0;
+        if (resident_full < 1 && !fits && ctx->mf_full_streamed_ok &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&streamed_full,
+                                                         reinterpret_cast<const void *>(&render_kernel<SRC_MFMA_STREAMED, true>),
+                                                         wg_threads_of(SRC_MFMA_STREAMED, true), mf_lds_streamed(true)) != hipSuccess)
+            streamed_full = 0;
+        (void)hipGetLastError();
+        ctx->mf_streamed_full = streamed_full;
         ctx->mf_usable = resident >= 1; // a device that cannot hold the workgroup scans with the packed filter
     }
     if ((rc = to_device(ctx, &ctx->d_mat_id, mid)) != RT_OK) return rc;
@@ -2074,15 +2099,15 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
         src = resident ? SRC_LDS_RESIDENT : SRC_LDS_STREAMED;
         lds += (size_t)(resident ? (ctx->n_quads > 0 ? ctx->n_quads : 1) : STREAM_QUADS) * 5 * sizeof(float4);
     }
-    // the general kernel's long sphere lists go through the matrix-core filter too when the table stays resident
-    const bool mf_full = full && ctx->mf_resident_full >= 1 && ctx->n_spheres >= ctx->mf_full_min;
+    // the general kernel's long sphere lists go through the matrix-core filter too
+    const bool mf_full = full && (ctx->mf_resident_full >= 1 || ctx->mf_streamed_full >= 1) && ctx->n_spheres >= ctx->mf_full_min;
     if (ctx->mf_usable && ctx->mf_wanted && (!full || mf_full)) {
-        // matrix-core filter: one table per workgroup in LDS, as many workgroups as stay resident
-        const bool fits = full || mf_lds_resident(ctx->mf.n_blocks) <= MF_LDS_BYTES;
+        // matrix-core filter: one table per workgroup in LDS (or two tiles of it), as many workgroups as stay resident
+        const bool fits = full ? ctx->mf_resident_full >= 1 : mf_lds_resident(ctx->mf.n_blocks) <= MF_LDS_BYTES;
         src = fits ? SRC_MFMA : SRC_MFMA_STREAMED;
         k.mf = ctx->mf;
-        lds = fits ? mf_lds_resident(ctx->mf.n_blocks, full) : MF_LDS_STREAMED;
-        const int resident = full ? ctx->mf_resident_full : ctx->mf_resident;
+        lds = fits ? mf_lds_resident(ctx->mf.n_blocks, full) : mf_lds_streamed(full);
+        const int resident = full ? (fits ? ctx->mf_resident_full : ctx->mf_streamed_full) : ctx->mf_resident;
         const int wpw = wg_threads_of(src, full) / 64;
         want = (items + wpw - 1) / wpw;
         cap = (long long)ctx->n_cus * resident;
@@ -2094,12 +2119,13 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
     const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, queue};
 #define RT_LAUNCH(S, L) hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, ka)
     if (src == SRC_MFMA) { if (full) RT_LAUNCH(SRC_MFMA, true); else RT_LAUNCH(SRC_MFMA, false); }
-    else if (src == SRC_MFMA_STREAMED) RT_LAUNCH(SRC_MFMA_STREAMED, false);
+    else if (src == SRC_MFMA_STREAMED) { if (full) RT_LAUNCH(SRC_MFMA_STREAMED, true); else RT_LAUNCH(SRC_MFMA_STREAMED, false); }
     else if (src == SRC_SCALAR) { if (full) RT_LAUNCH(SRC_SCALAR, true); else RT_LAUNCH(SRC_SCALAR, false); }
     else if (src == SRC_LDS_RESIDENT) { if (full) RT_LAUNCH(SRC_LDS_RESIDENT, true); else RT_LAUNCH(SRC_LDS_RESIDENT, false); }
     else { if (full) RT_LAUNCH(SRC_LDS_STREAMED, true); else RT_LAUNCH(SRC_LDS_STREAMED, false); }
 #undef RT_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
+    ctx->last_variant = src + (full ? 8 : 0);
     return RT_OK;
 }
 } // namespace
@@ -2175,6 +2201,7 @@ RT_API int rt_render_host(rt_ctx *ctx, const rt_params *p, uint8_t *h_rgba, floa
 RT_API uint64_t rt_device_allocations(const rt_ctx *ctx) { return ctx ? ctx->n_allocs : 0; }
 
 RT_API float rt_last_kernel_ms(const rt_ctx *ctx) { return ctx ? ctx->last_kernel_ms : 0.f; }
+RT_API int rt_last_kernel_variant(const rt_ctx *ctx) { return ctx ? ctx->last_variant : -1; }
 
 RT_API int rt_first_hit_ex(rt_ctx *ctx, int n_rays, const float *d_org, const float *d_dir, float tmin,
                            uint32_t flags, int32_t *d_id, float *d_t, float *d_normal, uint8_t *d_front,

@@ -277,8 +277,9 @@ __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *_
                                                    bool live, float tmin, int self_id, int lane, const CandQ &cq,
                                                    const float4 *__restrict__ sph, const float4 *__restrict__ rows,
                                                    float &best_t, int &best_id, SecClock &sec) {
-    constexpr int PER_THREAD = MF_TILE_BLOCKS * MF_BLOCK_WORDS / WG_THREADS_T; // 16-byte words of a tile per thread
-    static_assert(PER_THREAD * WG_THREADS_T == MF_TILE_BLOCKS * MF_BLOCK_WORDS, "a tile divides evenly over the workgroup");
+    constexpr int TILE = MF_TILE_BLOCKS * MF_BLOCK_WORDS;                  // 16-byte words of a tile
+    constexpr int PER_THREAD = (TILE + WG_THREADS_T - 1) / WG_THREADS_T;   // ... per thread
+    constexpr bool EVEN = PER_THREAD * WG_THREADS_T == TILE;               // else the last turn is for some threads only
     const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
     cq.slot[lane] = NO_HIT_KEY;
     int count = 0;
@@ -287,7 +288,8 @@ __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *_
     uint4v next[PER_THREAD];
     // the previous scan's readers of buffer 0 are done: every wave has passed the last barrier of that scan
 #pragma unroll
-    for (int k = 0; k < PER_THREAD; ++k) bufs[tid + k * WG_THREADS_T] = gtab[tid + k * WG_THREADS_T];
+    for (int k = 0; k < PER_THREAD; ++k)
+        if (EVEN || tid + k * WG_THREADS_T < TILE) bufs[tid + k * WG_THREADS_T] = gtab[tid + k * WG_THREADS_T];
     sec.mark(12); // tuning build: 12 = first tile and its barrier, 13 = the barriers between tiles
     __syncthreads();
     sec.mark(8);
@@ -295,14 +297,16 @@ __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *_
         if (t + 1 < n_tiles) {
             const uint4v *g = gtab + (size_t)(t + 1) * MF_TILE_BLOCKS * MF_BLOCK_WORDS;
 #pragma unroll
-            for (int k = 0; k < PER_THREAD; ++k) next[k] = g[tid + k * WG_THREADS_T];
+            for (int k = 0; k < PER_THREAD; ++k)
+                if (EVEN || tid + k * WG_THREADS_T < TILE) next[k] = g[tid + k * WG_THREADS_T];
         }
         mfma_scan_blocks(bufs + (t & 1) * MF_TILE_WORDS + lane, t * MF_TILE_BLOCKS, MF_TILE_BLOCKS, op, cq, count, lane, o, dh,
                          tmin, self_id, rows, sec);
         if (t + 1 < n_tiles) {
             uint4v *dst = bufs + ((t + 1) & 1) * MF_TILE_WORDS;
 #pragma unroll
-            for (int k = 0; k < PER_THREAD; ++k) dst[tid + k * WG_THREADS_T] = next[k];
+            for (int k = 0; k < PER_THREAD; ++k)
+                if (EVEN || tid + k * WG_THREADS_T < TILE) dst[tid + k * WG_THREADS_T] = next[k];
         }
         sec.mark(13);
         __syncthreads(); // the next tile is complete, and nobody still reads the buffer after it

@@ -301,6 +301,58 @@ def test_general_kernel_with_a_long_sphere_list_takes_the_matrix_core_filter(nam
     assert abs(a[2] - ref_rays) <= 4e-3 * ref_rays
 
 
+def _light_above(box):
+    from raytracer_amd.api import LIGHT_DTYPE
+    lights = np.zeros(1, dtype=LIGHT_DTYPE)
+    lights[0]["position"] = (0.3 * box[0], -0.2 * box[1], 3.0 * box[2] + 2.0)
+    lights[0]["ambient"] = (0.03, 0.03, 0.03)
+    lights[0]["diffuse"] = (0.5, 0.5, 0.45)
+    lights[0]["specular"] = (0.8, 0.8, 0.8)
+    lights[0]["view_pow"] = 16.0
+    return lights
+
+
+@pytest.mark.parametrize("n,variant", [(1473, 8 + 3), (2600, 8 + 4)])
+def test_general_kernel_streams_a_table_too_long_for_lds(n, variant, oracle64, monkeypatch):
+    """A lit scene (Camera::computeDirectLighting, reference src/Camera.cpp:161-178) of more spheres than a table
+    resident in LDS holds: the general kernel streams the table through LDS in tiles like the sphere-only kernel
+    does (its workgroup is smaller, so a table the sphere-only kernel already streams may still be resident for it:
+    the first case).  Which kernel ran is asked of the library; bytes, sums and ray counts equal the packed
+    filter's, and the frame is the oracle's."""
+    from raytracer_amd.api import FLAG_DIRECT_LIGHT
+
+    box = (30.0, 30.0, 4.0)
+    scene = _cloud("lit_streamed", n, 7, box=box, radii=(0.1, 0.5))
+    scene.lights = _light_above(box)
+    W, H, spp, depth = 96, 64, 12, 12
+    p = RenderParams(W, H, spp, depth, seed=4, flags=FLAG_DIRECT_LIGHT)
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        assert r.last_kernel_variant() == -1
+        a = r.render_host(p, want_accum=True)
+        assert r.last_kernel_variant() == variant  # general kernel, table resident (3) / streamed (4)
+        ms_mfma = r.last_kernel_ms()
+        r.render_host(RenderParams(W, H, spp, depth, seed=4))  # no lights asked for: the sphere-only kernel
+        assert r.last_kernel_variant() == 4
+    monkeypatch.setenv("RT_AMD_SPHERE_SOURCE", "scalar")
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        b = r.render_host(p, want_accum=True)
+        assert r.last_kernel_variant() == 8 + 2
+        ms_packed = r.last_kernel_ms()
+    assert a[2] == b[2], f"ray counts differ: {a[2]} vs {b[2]}"
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    ref, _, ref_rays = oracle64.render(scene, W, H, spp, depth, seed=4, direct_light=True)
+    diff = a[0][:, :, :3].astype(np.int32) - ref[:, :, :3].astype(np.int32)
+    close = float(np.mean(np.abs(diff) <= 1))
+    print(f"{n} spheres lit: kernel {ms_mfma:.2f} ms (packed filter {ms_packed:.2f} ms), rays {a[2]} vs oracle {ref_rays}, "
+          f"{100 * close:.2f} % of bytes within 1 of the oracle's, mean |difference| {np.abs(diff).mean():.3f}")
+    # 12 samples per pixel among thousands of small spheres: a path that grazes one goes the other way in the
+    # oracle's double arithmetic and moves its pixel by more than one step (the packed filter's frame is the same)
+    assert close >= 0.97 and np.abs(diff).mean() < 0.5
+    assert abs(a[2] - ref_rays) <= 4e-3 * ref_rays
+
+
 def test_single_ray_queries_through_the_table(oracle64):
     """SceneManager::hitClosest is asked one ray at a time by interactive callers (picking): a batch of one, of 63
     and of 65 rays through the matrix-core scan, where most lanes of a wave carry no ray."""
@@ -338,14 +390,8 @@ def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatc
         scene.camera = scenes.make_camera(c, dvec)
     p = RenderParams(80, 48, int(rng.choice([4, 16, 40])), int(rng.choice([3, 12, 50])), seed=seed)
     if lit:  # tools/stress_filters.py: the general kernel, with a light above the cloud
-        from raytracer_amd.api import FLAG_DIRECT_LIGHT, LIGHT_DTYPE
-        lights = np.zeros(1, dtype=LIGHT_DTYPE)
-        lights[0]["position"] = (0.3 * box[0], -0.2 * box[1], 3.0 * box[2] + 2.0)
-        lights[0]["ambient"] = (0.03, 0.03, 0.03)
-        lights[0]["diffuse"] = (0.5, 0.5, 0.45)
-        lights[0]["specular"] = (0.8, 0.8, 0.8)
-        lights[0]["view_pow"] = 16.0
-        scene.lights = lights
+        from raytracer_amd.api import FLAG_DIRECT_LIGHT
+        scene.lights = _light_above(box)
         p.flags = FLAG_DIRECT_LIGHT
     with Renderer(0) as r:
         r.set_scene(scene)
