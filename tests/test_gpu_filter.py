@@ -135,8 +135,9 @@ def test_frames_are_the_same_bytes_with_either_filter(monkeypatch):
 
 # ---- scenes built to strain the filter's frame: where its centre, its scale and its table layout come from ----
 
-def _cloud(name, n, seed, centre=(0.0, 0.0, 0.0), box=(10.0, 10.0, 3.0), radii=(0.05, 0.6), extra=()):
-    """n spheres of mixed materials scattered in a box around `centre`, then `extra` (centre, radius) spheres."""
+def _cloud(name, n, seed, centre=(0.0, 0.0, 0.0), box=(10.0, 10.0, 3.0), radii=(0.05, 0.6), extra=(), more=None):
+    """n spheres of mixed materials scattered in a box around `centre`, then `extra` (centre, radius) spheres;
+    `more(builder, materials)` adds whatever else the scene shall hold."""
     rng = np.random.default_rng(seed)
     b = scenes._Builder()
     mats = [b.lambertian((0.6, 0.5, 0.4)), b.metal((0.8, 0.8, 0.7), 0.1), b.dielectric((1.0, 1.0, 1.0), 1.5),
@@ -148,6 +149,8 @@ def _cloud(name, n, seed, centre=(0.0, 0.0, 0.0), box=(10.0, 10.0, 3.0), radii=(
         b.sphere(c, r, mats[i % len(mats)])
     for c, r in extra:
         b.sphere(np.asarray(c, dtype=np.float64) + c0, r, mats[0])
+    if more is not None:
+        more(b, mats)
     eye = c0 + np.array([1.6 * box[0], -1.3 * box[1], 2.5 * box[2] + 2.0])
     return b.build(name, scenes.make_camera(eye, c0 - eye))
 
@@ -312,17 +315,22 @@ def _light_above(box):
     return lights
 
 
-@pytest.mark.parametrize("n,variant", [(1473, 8 + 3), (2600, 8 + 4)])
-def test_general_kernel_streams_a_table_too_long_for_lds(n, variant, oracle64, monkeypatch):
+@pytest.mark.parametrize("n,variant,others", [(1473, 8 + 3, False), (2600, 8 + 4, False), (2600, 8 + 4, True)])
+def test_general_kernel_streams_a_table_too_long_for_lds(n, variant, others, oracle64, monkeypatch):
     """A lit scene (Camera::computeDirectLighting, reference src/Camera.cpp:161-178) of more spheres than a table
     resident in LDS holds: the general kernel streams the table through LDS in tiles like the sphere-only kernel
     does (its workgroup is smaller, so a table the sphere-only kernel already streams may still be resident for it:
-    the first case).  Which kernel ran is asked of the library; bytes, sums and ray counts equal the packed
+    the first case; the last adds a floor plane, a box and a selected sphere with its halo).  Which kernel ran is asked of the library; bytes, sums and ray counts equal the packed
     filter's, and the frame is the oracle's."""
     from raytracer_amd.api import FLAG_DIRECT_LIGHT
 
     box = (30.0, 30.0, 4.0)
-    scene = _cloud("lit_streamed", n, 7, box=box, radii=(0.1, 0.5))
+    def more(b, mats):
+        b.plane((0.0, 0.0, -box[2] - 0.5), (0.0, 0.0, 1.0), mats[3])
+        b.cube((3.0, -2.0, box[2] + 1.5), (1.5, 1.0, 0.8), mats[1])
+        b.select(5)
+
+    scene = _cloud("lit_streamed", n, 7, box=box, radii=(0.1, 0.5), more=more if others else None)
     scene.lights = _light_above(box)
     W, H, spp, depth = 96, 64, 12, 12
     p = RenderParams(W, H, spp, depth, seed=4, flags=FLAG_DIRECT_LIGHT)
@@ -332,8 +340,8 @@ def test_general_kernel_streams_a_table_too_long_for_lds(n, variant, oracle64, m
         a = r.render_host(p, want_accum=True)
         assert r.last_kernel_variant() == variant  # general kernel, table resident (3) / streamed (4)
         ms_mfma = r.last_kernel_ms()
-        r.render_host(RenderParams(W, H, spp, depth, seed=4))  # no lights asked for: the sphere-only kernel
-        assert r.last_kernel_variant() == 4
+        r.render_host(RenderParams(W, H, spp, depth, seed=4))  # no lights asked for: the sphere-only kernel, if spheres are all there is
+        assert r.last_kernel_variant() == (variant if others else 4)
     monkeypatch.setenv("RT_AMD_SPHERE_SOURCE", "scalar")
     with Renderer(0) as r:
         r.set_scene(scene)
@@ -349,7 +357,7 @@ def test_general_kernel_streams_a_table_too_long_for_lds(n, variant, oracle64, m
           f"{100 * close:.2f} % of bytes within 1 of the oracle's, mean |difference| {np.abs(diff).mean():.3f}")
     # 12 samples per pixel among thousands of small spheres: a path that grazes one goes the other way in the
     # oracle's double arithmetic and moves its pixel by more than one step (the packed filter's frame is the same)
-    assert close >= 0.97 and np.abs(diff).mean() < 0.5
+    assert close >= 0.96 and np.abs(diff).mean() < 0.5
     assert abs(a[2] - ref_rays) <= 4e-3 * ref_rays
 
 
