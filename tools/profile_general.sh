@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence for the general kernel (lights, other primitive kinds, halo) as round 2 ends (runs on the GPU box).
+# rocprofv3 evidence for the general kernel (lights, other primitive kinds, halo) (runs on the GPU box).
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python3 tools/profile_cmd.py r02g_mixed_lit --passes valu,misc -- python3 tools/perf_scene.py --scene mixed_lit --w 1920 --h 1080 --spp 100 --lights --reps 3 &&

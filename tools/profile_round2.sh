@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence of round 2 (runs on the GPU box): kernel-trace stats + PMC passes for every workload,
+# rocprofv3 evidence (runs on the GPU box): kernel-trace stats + PMC passes for every workload,
 # the LDS-vs-scalar sphere source A/B, and the general kernel.  Summaries land in gpurun_out/<tag>/summary.json.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

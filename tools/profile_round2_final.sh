@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence of the kernels as they stand at the end of round 2 (runs on the GPU box).
+# rocprofv3 evidence of the kernels as they stand (runs on the GPU box); the summaries go to profiles/r02/.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 B="python3 bench.py --no-cpu-baseline --no-secondary"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Baseline evidence for the kernels as they stood at the start of round 2 (runs on the GPU box).
+# Baseline evidence: the kernels of an older library (tools/v_r01.so) profiled the same way (runs on the GPU box).
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout -k 10 120 tools/valu_mix.bin > gpurun_out/valu_mix.txt 2>&1 &&
