@@ -1,5 +1,5 @@
 #!/bin/bash
-# Baseline evidence: the kernels of an older library (tools/v_r01.so) profiled the same way (runs on the GPU box).
+# Baseline evidence: the tree as checked out profiled workload by workload (runs on the GPU box); tags base_*.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout -k 10 120 tools/valu_mix.bin > gpurun_out/valu_mix.txt 2>&1 &&
