@@ -50,7 +50,8 @@ constexpr int MF_MIN_SPHERES = 16;           // scenes get a matrix-core filter 
 constexpr int FULL_SCALAR_MIN_SPHERES = 128;  // the general kernel takes sphere words from LDS below this many spheres
 constexpr int STREAM_QUADS = 512;            // quads (4 spheres, 80 B) per streamed LDS tile (40 KiB)
 constexpr int SLOT_WORDS = 3 * MAX_TILE_PX;  // one tile slot's accumulators: r, g, b planes of 64-bit sums
-constexpr int WAVE_LDS_WORDS = 2 * SLOT_WORDS + 8; // two slots and their tile descriptors
+constexpr int PRIM_LIST_CAP = 16;             // spheres a tile's primary rays may have to be tested against (more: they take the scan)
+constexpr int WAVE_LDS_WORDS = 2 * SLOT_WORDS + 8 + PRIM_LIST_CAP; // two slots, their tile descriptors and their primary-ray lists
 constexpr size_t ACC_BYTES = WAVES_PER_WG * WAVE_LDS_WORDS * sizeof(unsigned long long); // per-wave accumulators
 // per-wave candidate queue and closest-hit slots of the deferred sphere decisions (rt_device.h)
 constexpr size_t CQ_BYTES = WAVES_PER_WG * (CAND_CAP * sizeof(unsigned) + 64 * sizeof(unsigned long long));
@@ -144,6 +145,7 @@ struct KParams {
     int n_quads;     // sphere quads to scan (padding included)
     int n_spheres;   // spheres of the scene
     int n_lights;    // lights shaded at every hit (0 unless RT_FLAG_DIRECT_LIGHT)
+    int prim_min;    // primary-ray lists: a scan runs when at least this many lanes need one (0: no lists, every ray takes the scan)
     MfmaFrame mf;    // frame of the matrix-core filter table (SRC_MFMA)
     float inv_w, inv_h;
     float cam[12];   // center, upper_left, right, down
@@ -335,6 +337,53 @@ __device__ __forceinline__ Tile decode_item(const P &p, unsigned item) {
     return t;
 }
 
+// The spheres a tile's primary rays can meet (Camera::genRay, src/Camera.cpp:124-135: every ray starts at the camera
+// centre and passes through the tile's patch of the viewport), by a cone around the pyramid those rays fill: axis
+// through the patch's middle, opening angle that of its farthest corner plus 2 %.  A sphere is listed when its
+// centre lies within |r| (plus 0.1 % and 10^-4 of its distance) of the cone, or when the camera is inside it.  The
+// test errs towards listing; what is listed is decided exactly.  Whole wave; returns the length of the list, or -1
+// when it would be longer than PRIM_LIST_CAP (the tile's primary rays then take the scan).
+template <class P>
+__device__ __forceinline__ int list_primary_candidates(const P &p, const Tile &t, const float4 *__restrict__ sph, int n,
+                                                       int *list, int lane) {
+    const V3 ul = mk(p.cam[3], p.cam[4], p.cam[5]), right = mk(p.cam[6], p.cam[7], p.cam[8]), down = mk(p.cam[9], p.cam[10], p.cam[11]);
+    const V3 c = mk(p.cam[0], p.cam[1], p.cam[2]);
+    const float fx0 = (float)t.x0 * p.inv_w, fx1 = (float)(t.x0 + t.vw) * p.inv_w;
+    const float fy0 = (float)t.y0 * p.inv_h, fy1 = (float)(t.y0 + t.vh) * p.inv_h;
+    const V3 base = ul - c;
+    const V3 q00 = normalized(madd(madd(base, right, fx0), down, fy0)), q10 = normalized(madd(madd(base, right, fx1), down, fy0));
+    const V3 q01 = normalized(madd(madd(base, right, fx0), down, fy1)), q11 = normalized(madd(madd(base, right, fx1), down, fy1));
+    const V3 axis = normalized(q00 + q10 + q01 + q11);
+    const float cmin = fminf(fminf(dot(q00, axis), dot(q10, axis)), fminf(dot(q01, axis), dot(q11, axis)));
+    const float sin_t = sqrtf(fmaxf(1.0f - cmin * cmin, 0.0f)) * 1.02f + 1.0e-6f;
+    // a pyramid wider than a quarter turn (or a degenerate camera) gets no list
+    if (!(cmin > 0.0f) || !(sin_t < 0.7f)) return -1;
+    const float cos_t = sqrtf(1.0f - sin_t * sin_t);
+    int count = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        bool pass = false;
+        if (i < n) {
+            const float4 sp = sph[i];
+            const V3 v = mk(sp.x - c.x, sp.y - c.y, sp.z - c.z);
+            const float along = dot(v, axis), d2 = dot(v, v);
+            const float perp = sqrtf(fmaxf(d2 - along * along, 0.0f));
+            const float dist = sqrtf(d2);
+            const float reach = fabsf(sp.w) * 1.001f + 1.0e-4f * dist;
+            // anything not provably outside is listed: a NaN fails the comparison and passes
+            pass = !(perp * cos_t - along * sin_t > reach) || !(dist > reach);
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) {
+            const int at = count + lane_rank(m);
+            if (at < PRIM_LIST_CAP) list[at] = i;
+        }
+        count += (int)__popcll(m);
+        if (count > PRIM_LIST_CAP) return -1;
+    }
+    return count;
+}
+
 // Persistent render kernel.  Work items are pixel tiles (all samples of 1 to 256 pixels,
 // a couple of thousand samples each); every wave pulls items from one global counter until
 // it runs dry, so the grid stays busy however uneven the image is.  A wave holds up to TWO
@@ -377,7 +426,13 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     unsigned long long *acc = acc_all + wave * WAVE_LDS_WORDS;
-    int *desc = reinterpret_cast<int *>(acc + 2 * SLOT_WORDS); // slot s: desc[8 s ...] = x0, y0, vw, vh, row0
+    int *desc = reinterpret_cast<int *>(acc + 2 * SLOT_WORDS); // slot s: desc[8 s ...] = x0, y0, vw, vh, row0, length of its primary-ray list
+    int *plist = desc + 16;                                    // slot s: plist[PRIM_LIST_CAP s ...] = sphere indices
+    // Primary rays of a tile all start at the camera and pass through the tile's patch of the viewport: the
+    // spheres that meet the cone around that pyramid are listed once per tile, and a new sample's primary ray
+    // is decided against the list at once, by the very decision the scan's candidates get.  The scan is then left to
+    // bounced rays, and runs only when enough lanes hold one; meanwhile the wave shades primary hits.
+    constexpr bool PRIM = SRC == SRC_MFMA && !FULL;
     CandQ cq;
     cq.slot = reinterpret_cast<unsigned long long *>(smem + acc_bytes_of(SRC, FULL)) + wave * 64;
     cq.ent = reinterpret_cast<unsigned *>(smem + acc_bytes_of(SRC, FULL) + NW * 64 * sizeof(unsigned long long)) + wave * cand_cap_of(SRC);
@@ -416,6 +471,8 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
     pt.depth = 0;
     pt.self_id = -1;
     unsigned long long my_rays = 0;
+    float pre_t = 0.f; // closest hit of the lane's primary ray, decided from its tile's list ...
+    int pre_id = -2;   // ... and its sphere (-1: none); -2: the lane's ray takes the scan
     LightState ls;
     ls.light_i = -1;
     ls.hp = ls.hn = ls.nxt_o = ls.nxt_d = ls.att = mk(0, 0, 0);
@@ -446,9 +503,18 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
 
         RT_SEC(0); // ray set-up and the scan
         const bool in_shadow = FULL && ls.light_i >= 0;
-        const bool active = pt.pix >= 0 && (pt.depth > 0 || in_shadow);
+        bool active = pt.pix >= 0 && (pt.depth > 0 || in_shadow);
         // a path with no depth left (max_depth == 0) contributes black and ends at once
         bool finished = pt.pix >= 0 && pt.depth <= 0 && !in_shadow;
+        // lanes whose primary hit is known need no scan; while fewer than prim_min lanes need one and some
+        // primary hit waits to be shaded, the wave shades those and the other rays wait a turn
+        const bool pre = PRIM && active && pre_id != -2;
+        bool skip_scan = false;
+        if (PRIM && KP.prim_min > 0) {
+            const unsigned long long need = __ballot(active && !pre);
+            skip_scan = __ballot(pre) != 0 && (int)__popcll(need) < KP.prim_min;
+            if (skip_scan) active = pre;
+        }
 
 #if defined(RT_STATS) && !defined(RT_STATS_TIMES_ONLY)
         {
@@ -477,7 +543,14 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
         } else if constexpr (SRC == SRC_LDS_RESIDENT) {
             if (active) scan_lds(lds_sph, lds_r2, nquads, 0, rk, pt.o, pt.dh, tmin, pt.self_id, best_t, best_id);
         } else if constexpr (SRC == SRC_MFMA) {
-            scan_mfma(lds_tab, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph, KS.mf_rows, best_t, best_id, sec);
+            if (!skip_scan)
+                scan_mfma(lds_tab, KP.mf, pt.o, pt.dh, active && !pre, tmin, pt.self_id, lane, cq, KS.sph, KS.mf_rows, best_t,
+                          best_id, sec);
+            if (pre) {
+                best_t = pre_t;
+                best_id = pre_id;
+                pre_id = -2;
+            }
         } else if constexpr (SRC == SRC_MFMA_STREAMED) {
             scan_mfma_streamed<WGT>(lds_tab, KS.mf_table, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph,
                                     KS.mf_rows, best_t, best_id, sec);
@@ -683,6 +756,10 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
                     int *d = desc + 8 * fill;
                     d[0] = tile.x0; d[1] = tile.y0; d[2] = tile.vw; d[3] = tile.vh; d[4] = tile.row0;
                 }
+                if (PRIM && KP.prim_min > 0) {
+                    const int n_listed = list_primary_candidates(KP, tile, KS.sph, KP.n_spheres, plist + PRIM_LIST_CAP * fill, lane);
+                    if (lane == 0) desc[8 * fill + 5] = n_listed;
+                }
 #ifdef RT_STATS
                 t_fetch[fill] = wall_clock64();
                 cur_item[fill] = it;
@@ -738,6 +815,27 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
                 gen_ray(KP, px, py, u01(w0), u01(w1), pt.o, nd);
                 if (FULL) ls.light_i = -1;
                 set_dir(pt, nd);
+                if (PRIM && KP.prim_min > 0 && pt.depth > 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the list was written by other lanes
+                    const int slot = pt.pix >= SLOT_WORDS ? 1 : 0;
+                    const int n_listed = desc[8 * slot + 5];
+                    if (n_listed >= 0) {
+                        const int *mine = plist + PRIM_LIST_CAP * slot;
+                        const float tmin0 = TMIN * pt.len;
+                        unsigned long long key = NO_HIT_KEY;
+                        for (int k = 0; k < n_listed; ++k) {
+                            const int sidx = mine[k];
+                            const float4 sp = KS.sph[sidx];
+                            const float cand = sphere_root(pt.o, pt.dh, sp.x, sp.y, sp.z, sp.w * sp.w, tmin0);
+                            if (cand > tmin0 && cand < __builtin_inff()) {
+                                const unsigned long long kk = ((unsigned long long)__float_as_uint(cand) << 32) | (unsigned long long)(unsigned)sidx;
+                                key = kk < key ? kk : key;
+                            }
+                        }
+                        pre_t = key != NO_HIT_KEY ? __uint_as_float((unsigned)(key >> 32)) : __builtin_inff();
+                        pre_id = key != NO_HIT_KEY ? (int)(unsigned)key : -1;
+                    }
+                }
             } else {
                 V3 att, no;
                 scatter(__float_as_uint(at.w), mk(at.x, at.y, at.z), ef.w, ior, pt.d, h, u01(w0), u01(w1), u01(w2), att,
@@ -1312,6 +1410,7 @@ struct rt_ctx {
     int mf_full_min = 24; // sphere count from which the general kernel takes the table (measured: even at 16, 5 % ahead at 32, 26 % at 64; tuning: RT_AMD_MF_FULL_MIN)
     int mf_resident_full = 0; // the same for the general kernel's variant (0: its table does not fit, or no such device)
     bool mf_full_streamed_ok = true;
+    int prim_min = 64; // primary-ray lists of the sphere-only matrix-core kernel: lanes that must need a scan for one to run (0: off; tuning: RT_AMD_PRIM_MIN)
     int last_variant = -1; // sphere source of the last render launch, + 8 for the general kernel
     int mf_streamed_full = 0; // the same for the general kernel's variant with the table streamed through LDS
     unsigned char *d_queue = nullptr; // ring of work-item counters of the persistent render kernel
@@ -1573,6 +1672,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
     // where the scan takes sphere data from: scalar loads (default, fastest measured) or LDS
     // broadcast reads ("lds": resident copy for small scenes, streamed tiles for large ones)
     if (const char *t = getenv("RT_AMD_MF_FULL_MIN")) { int v = atoi(t); if (v >= MF_MIN_SPHERES) ctx->mf_full_min = v; }
+    if (const char *t = getenv("RT_AMD_PRIM_MIN")) { int v = atoi(t); if (*t >= '0' && *t <= '9' && v <= 64) ctx->prim_min = v; }
     if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (*t >= '0' && *t <= '9' && v <= 6) ctx->force_tile = v; }
     const char *src = getenv("RT_AMD_SPHERE_SOURCE");
     ctx->scalar_source = !(src && strcmp(src, "lds") == 0);
@@ -2116,6 +2216,7 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
     } else {
         memset(&k.mf, 0, sizeof k.mf);
     }
+    k.prim_min = (src == SRC_MFMA && !full) ? ctx->prim_min : 0;
     const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, queue};
 #define RT_LAUNCH(S, L) hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, ka)
     if (src == SRC_MFMA) { if (full) RT_LAUNCH(SRC_MFMA, true); else RT_LAUNCH(SRC_MFMA, false); }

@@ -171,9 +171,9 @@ def _strain_scenes():
         # the smallest scene that gets a table and one streamed through LDS in tiles
         "sixteen": _cloud("sixteen", 16, 6),
         "streamed": _cloud("streamed", 2600, 7, box=(30.0, 30.0, 4.0), radii=(0.1, 0.5)),
-        # the largest table that stays resident in LDS (46 blocks of 32) and the first that does not
-        "edge_resident": _cloud("edge_resident", 1472, 8, box=(25.0, 25.0, 4.0), radii=(0.1, 0.5)),
-        "edge_streamed": _cloud("edge_streamed", 1473, 8, box=(25.0, 25.0, 4.0), radii=(0.1, 0.5)),
+        # the largest table that stays resident in LDS (45 blocks of 32) and the first that does not
+        "edge_resident": _cloud("edge_resident", 1440, 8, box=(25.0, 25.0, 4.0), radii=(0.1, 0.5)),
+        "edge_streamed": _cloud("edge_streamed", 1441, 8, box=(25.0, 25.0, 4.0), radii=(0.1, 0.5)),
     }
 
 
@@ -190,7 +190,7 @@ def test_strained_frames_drop_no_hit(name):
         info = r.filter_describe()
         assert info["in_use"] and info["n_rows"] >= len(scene.spheres) - len(info["big"])
         if name.startswith("edge"):
-            assert not info["big"] and info["n_rows"] == (1472 if name == "edge_resident" else 1536)  # whole tiles of 16 blocks
+            assert not info["big"] and info["n_rows"] == (1440 if name == "edge_resident" else 1536)  # whole tiles of 16 blocks
         org, d = _rays(scene, 4096, rng, spread=info["radius"])
         # a few origins very far out, aimed back at the cloud
         far = rng.random(len(org)) < 0.05
@@ -382,7 +382,7 @@ def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatc
     inside or outside the cloud): the matrix-core filter and the packed filter select the same hits, so frames,
     radiance sums and ray counts are equal."""
     rng = np.random.default_rng(1000 + seed)
-    n = int(rng.choice([16, 17, 31, 33, 64, 200, 485, 1000, 1472, 1473, 2000, 3000]))
+    n = int(rng.choice([16, 17, 31, 33, 64, 200, 485, 1000, 1440, 1441, 2000, 3000]))
     rmax = float(rng.uniform(0.1, 1.0))
     # a box the spheres fill well enough for paths to bounce: about six largest-sphere areas of floor per sphere
     side, stretch = float(np.sqrt(n * 6.0) * rmax), float(rng.uniform(0.5, 2.0))

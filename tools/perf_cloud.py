@@ -1,9 +1,9 @@
-"""Tuning aid: kernel time of sphere clouds of given sizes (the table resident in LDS up to 1472 spheres, streamed beyond)."""
+"""Tuning aid: kernel time of sphere clouds of given sizes (the table resident in LDS up to 1440 spheres, streamed beyond)."""
 import sys
 import numpy as np
 sys.path.insert(0, '.')
 from raytracer_amd import Renderer, RenderParams, scenes
-for n in [int(x) for x in sys.argv[1:]] or [1000, 1472, 1473, 2000, 3000]:
+for n in [int(x) for x in sys.argv[1:]] or [1000, 1440, 1441, 2000, 3000]:
     rng = np.random.default_rng(1)
     b = scenes._Builder()
     mats = [b.lambertian((0.6, 0.5, 0.4)), b.metal((0.8, 0.8, 0.7), 0.1), b.dielectric((1.0, 1.0, 1.0), 1.5)]
