@@ -157,7 +157,14 @@ class Job:
             # arithmetic is the dense f16 MFMA peak, priced at the products the kernel really issues for the
             # rays it traced.  The algorithmic rate of the reference's fp32 formulation is given beside it, with
             # the FP32 vector peak that bounded the packed-FP32 form of the same filter.
-            mfma = rays_per_launch * FLOP_PER_ROW_MFMA * (info.get("table_rows") or info["n_rows"]) / (kern_ms * 1e-3) / 1e12
+            # what the matrix pipe was given: scans x 64 lanes x table rows.  Primary rays decided from their tile's
+            # list take no scan, and a scan is issued for all 64 lanes of its wave whether or not each holds a ray.
+            # The count comes from one more frame rendered through the host entry point after the timed region.
+            rows = info.get("table_rows") or info["n_rows"]
+            self.p.seed = 0
+            self.r.render_host(self.p)
+            scans = self.r.last_scans()
+            mfma = scans * 64 * FLOP_PER_ROW_MFMA * rows / (kern_ms * 1e-3) / 1e12
             return {
                 "bound": "mfma",
                 "achieved": round(mfma, 3),
@@ -176,8 +183,9 @@ class Job:
                 "traffic_source": traffic_src,
                 "kernel": "render_kernel",
                 "kernel_ms": round(kern_ms, 3),
-                "flop_model": f"matrix: rays*{FLOP_PER_ROW_MFMA}*{(info.get('table_rows') or info['n_rows'])} table rows; algorithmic: "
-                              f"rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}); rays/launch={rays_per_launch:.0f}",
+                "flop_model": f"matrix: scans*64 lanes*{FLOP_PER_ROW_MFMA}*{rows} table rows; algorithmic: "
+                              f"rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}); rays/launch={rays_per_launch:.0f}, scans/launch={scans}",
+                "scanned_ray_share": round(scans * 64 / max(rays_per_launch, 1), 4),
             }
         return {
             "bound": "valu_fp32",

@@ -232,6 +232,12 @@ uint64_t rt_device_allocations(const rt_ctx *ctx);
  * nothing in the reference; for tests and tuning. */
 int rt_last_kernel_variant(const rt_ctx *ctx);
 
+/* Scans the waves of the last rt_render_host() call's kernel ran: one scan finds the closest sphere for the
+ * (up to) 64 rays a wave holds, so 64 x this x the table rows of rt_filter_describe() is the number of filter
+ * values the matrix cores produced.  Primary rays decided from their tile's list of spheres take no scan.
+ * Replaces nothing in the reference; for measurement. */
+uint64_t rt_last_scans(const rt_ctx *ctx);
+
 /* First-hit flags */
 enum {
     RT_FH_REFINE = 1u << 0,  /* re-test numerically ambiguous rays in fp64 so that the

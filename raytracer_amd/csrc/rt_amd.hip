@@ -173,6 +173,7 @@ struct KArgs {
     uchar4 *rgba;
     float4 *accum;                // may be null
     unsigned long long *rays_out; // may be null
+    unsigned long long *scans_out; // may be null: receives the number of scans the waves ran (64 lanes each)
     unsigned *queue;              // work counter, zero at launch
 };
 
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
 #define rgba (kargs->rgba)
 #define accum (kargs->accum)
 #define rays_out (kargs->rays_out)
+#define scans_out (kargs->scans_out)
 #define queue (kargs->queue)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // per-wave state first (two accumulator slots of 3 channels x 64 pixels and their tile
@@ -471,6 +473,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
     pt.depth = 0;
     pt.self_id = -1;
     unsigned long long my_rays = 0;
+    unsigned n_scans = 0; // wave-uniform
     float pre_t = 0.f; // closest hit of the lane's primary ray, decided from its tile's list ...
     int pre_id = -2;   // ... and its sphere (-1: none); -2: the lane's ray takes the scan
     LightState ls;
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
         // ---- closest hit over all spheres (SceneManager::hitClosest, src/RayTracer.cpp:77-82) ----
         float best_t = __builtin_inff(); // in units of |d|
         int best_id = -1;
+        if (!skip_scan) n_scans++;
         const float tmin = TMIN * pt.len;
         RayK rk = make_rayk(pt.o, pt.dh);
         if constexpr (SRC == SRC_LDS_STREAMED) {
@@ -886,11 +890,13 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
         for (int off = 32; off > 0; off >>= 1) my_rays += __shfl_down(my_rays, off, 64);
         if (lane == 0 && my_rays) atomicAdd(rays_out, my_rays);
     }
+    if (scans_out && lane == 0 && n_scans) atomicAdd(scans_out, (unsigned long long)n_scans);
 #undef KP
 #undef KS
 #undef rgba
 #undef accum
 #undef rays_out
+#undef scans_out
 #undef queue
 }
 
@@ -1443,7 +1449,9 @@ struct rt_ctx {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     float last_kernel_ms = 0.f;
     void *frame_rgba = nullptr, *frame_accum = nullptr;
-    uint64_t *frame_rays = nullptr;
+    uint64_t *frame_rays = nullptr; // closest-hit queries of the frame being rendered for the host, then its scans
+    bool count_scans = false;        // the next launch reports its scans in frame_rays[1]
+    uint64_t last_scans = 0;
     // rt_first_hit_ex_host's staging buffers
     void *fh_org = nullptr, *fh_dir = nullptr, *fh_id = nullptr, *fh_t = nullptr, *fh_nrm = nullptr, *fh_front = nullptr,
          *fh_exp = nullptr;
@@ -1539,7 +1547,7 @@ extern "C" __attribute__((visibility("default"))) int rt_debug_stats(unsigned lo
 }
 #endif
 
-RT_API int rt_version(void) { return 103; }
+RT_API int rt_version(void) { return 104; }
 
 RT_API void rt_rng4(uint32_t pixel, uint32_t sample, uint32_t call, uint32_t seed, uint32_t out[4]) {
     rng4(pixel, sample, call, seed, out[0], out[1], out[2], out[3]);
@@ -1662,7 +1670,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
         ctx->n_cus = prop.multiProcessorCount;
     if (scratch_ptr(device, &ctx->d_scratch) != hipSuccess ||
         reserve(ctx, (void **)&ctx->d_queue, QUEUE_SLOTS * QUEUE_SLOT_BYTES) != hipSuccess ||
-        reserve(ctx, (void **)&ctx->frame_rays, 8) != hipSuccess ||
+        reserve(ctx, (void **)&ctx->frame_rays, 16) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
         rt_destroy(ctx);
@@ -2217,7 +2225,8 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
         memset(&k.mf, 0, sizeof k.mf);
     }
     k.prim_min = (src == SRC_MFMA && !full) ? ctx->prim_min : 0;
-    const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, queue};
+    const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, ctx->count_scans ? (unsigned long long *)(ctx->frame_rays + 1) : nullptr, queue};
+    ctx->count_scans = false;
 #define RT_LAUNCH(S, L) hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, ka)
     if (src == SRC_MFMA) { if (full) RT_LAUNCH(SRC_MFMA, true); else RT_LAUNCH(SRC_MFMA, false); }
     else if (src == SRC_MFMA_STREAMED) { if (full) RT_LAUNCH(SRC_MFMA_STREAMED, true); else RT_LAUNCH(SRC_MFMA_STREAMED, false); }
@@ -2260,7 +2269,8 @@ int render_into_frame(rt_ctx *ctx, const rt_params *p, bool want_accum, const fl
     const size_t npx = rows * (size_t)p->width;
     HIP_TRY(ctx, reserve(ctx, &ctx->frame_rgba, npx * 4));
     if (want_accum) HIP_TRY(ctx, reserve(ctx, &ctx->frame_accum, npx * 16));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->frame_rays, 0, 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->frame_rays, 0, 16, ctx->stream));
+    ctx->count_scans = true;
     HIP_TRY(ctx, hipMemsetAsync(ctx->frame_rgba, 0, npx * 4, ctx->stream));
     if (want_accum) {
         if (h_accum_in)
@@ -2294,6 +2304,7 @@ RT_API int rt_render_host(rt_ctx *ctx, const rt_params *p, uint8_t *h_rgba, floa
     HIP_TRY(ctx, hipMemcpyAsync(h_rgba, ctx->frame_rgba, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (h_accum) HIP_TRY(ctx, hipMemcpyAsync(h_accum, ctx->frame_accum, npx * 16, hipMemcpyDeviceToHost, ctx->stream));
     if (h_rays) HIP_TRY(ctx, hipMemcpyAsync(h_rays, ctx->frame_rays, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&ctx->last_scans, ctx->frame_rays + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev_start, ctx->ev_stop));
     return RT_OK;
@@ -2303,6 +2314,7 @@ RT_API uint64_t rt_device_allocations(const rt_ctx *ctx) { return ctx ? ctx->n_a
 
 RT_API float rt_last_kernel_ms(const rt_ctx *ctx) { return ctx ? ctx->last_kernel_ms : 0.f; }
 RT_API int rt_last_kernel_variant(const rt_ctx *ctx) { return ctx ? ctx->last_variant : -1; }
+RT_API uint64_t rt_last_scans(const rt_ctx *ctx) { return ctx ? ctx->last_scans : 0; }
 
 RT_API int rt_first_hit_ex(rt_ctx *ctx, int n_rays, const float *d_org, const float *d_dir, float tmin,
                            uint32_t flags, int32_t *d_id, float *d_t, float *d_normal, uint8_t *d_front,

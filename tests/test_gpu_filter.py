@@ -414,3 +414,41 @@ def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatc
     # the scene is in view: paths bounce, and the frame is not one colour
     assert a[2] > 1.003 * p.width * p.height * p.samples_per_pixel, (n, a[2])
     assert len(np.unique(a[0][:, :, :3].reshape(-1, 3), axis=0)) > 50, n
+
+
+@pytest.mark.parametrize("case", ["c3_small", "few_samples", "one_pixel_tiles", "inside", "behind", "wide"])
+def test_primary_ray_lists_change_no_byte(case, monkeypatch):
+    """The sphere-only matrix-core kernel decides a new sample's primary ray (Camera::genRay, reference
+    src/Camera.cpp:124-135: from the camera centre through the pixel) against the spheres its tile's pyramid can meet,
+    listed once per tile, and runs scans for bounced rays only.  With the lists switched off (every ray takes the scan)
+    frames, radiance sums and ray counts are the same; with them the kernel runs fewer scans, and every ray that is
+    not a listed primary still gets one."""
+    scene = scenes.by_name("random_spheres")
+    W, H, spp, depth = 160, 96, 24, 50
+    if case == "few_samples":      # 8x8-pixel tiles: wide pyramids, long lists, some of them too long
+        spp = 3
+    elif case == "one_pixel_tiles":
+        W, H, spp = 48, 30, 1100
+    elif case == "inside":         # the camera inside one of the large spheres (glass), looking along the ground
+        scene.camera = scenes.make_camera((0.0, 1.0, 0.0), (1.0, -0.1, 0.3))
+    elif case == "behind":         # most of the scene behind the camera
+        scene.camera = scenes.make_camera((3.0, 0.6, 1.0), (1.0, 0.05, 0.2))
+    elif case == "wide":           # a low frame of coarse pixels: every tile's list is too long, all rays take the scan
+        W, H = 400, 16
+    p = RenderParams(W, H, spp, depth, seed=21)
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        a = r.render_host(p, want_accum=True)
+        assert r.last_kernel_variant() == 3
+        scans_with = r.last_scans()
+    monkeypatch.setenv("RT_AMD_PRIM_MIN", "0")
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        b = r.render_host(p, want_accum=True)
+        scans_without = r.last_scans()
+    assert a[2] == b[2], f"ray counts differ: {a[2]} vs {b[2]}"
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    primaries = W * H * spp
+    print(f"{case}: rays {a[2]} ({primaries} primary), scans {scans_with} with lists, {scans_without} without")
+    assert 64 * scans_without >= a[2] and 64 * scans_with >= a[2] - primaries
+    assert scans_with == scans_without if case == "wide" else scans_with < 0.8 * scans_without
