@@ -434,7 +434,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
     // spheres that meet the cone around that pyramid are listed once per tile, and a new sample's primary ray
     // is decided against the list at once, by the very decision the scan's candidates get.  The scan is then left to
     // bounced rays, and runs only when enough lanes hold one; meanwhile the wave shades primary hits.
-    constexpr bool PRIM = SRC == SRC_MFMA && !FULL;
+    constexpr bool PRIM = SRC == SRC_MFMA;
     CandQ cq;
     cq.slot = reinterpret_cast<unsigned long long *>(smem + acc_bytes_of(SRC, FULL)) + wave * 64;
     cq.ent = reinterpret_cast<unsigned *>(smem + acc_bytes_of(SRC, FULL) + NW * 64 * sizeof(unsigned long long)) + wave * cand_cap_of(SRC);
@@ -2224,7 +2224,7 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
     } else {
         memset(&k.mf, 0, sizeof k.mf);
     }
-    k.prim_min = (src == SRC_MFMA && !full) ? ctx->prim_min : 0;
+    k.prim_min = src == SRC_MFMA ? ctx->prim_min : 0;
     const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, ctx->count_scans ? (unsigned long long *)(ctx->frame_rays + 1) : nullptr, queue};
     ctx->count_scans = false;
 #define RT_LAUNCH(S, L) hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, ka)
