@@ -434,7 +434,7 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
     // spheres that meet the cone around that pyramid are listed once per tile, and a new sample's primary ray
     // is decided against the list at once, by the very decision the scan's candidates get.  The scan is then left to
     // bounced rays, and runs only when enough lanes hold one; meanwhile the wave shades primary hits.
-    constexpr bool PRIM = SRC == SRC_MFMA;
+    constexpr bool PRIM = is_mfma(SRC);
     CandQ cq;
     cq.slot = reinterpret_cast<unsigned long long *>(smem + acc_bytes_of(SRC, FULL)) + wave * 64;
     cq.ent = reinterpret_cast<unsigned *>(smem + acc_bytes_of(SRC, FULL) + NW * 64 * sizeof(unsigned long long)) + wave * cand_cap_of(SRC);
@@ -516,6 +516,9 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
         if (PRIM && KP.prim_min > 0) {
             const unsigned long long need = __ballot(active && !pre);
             skip_scan = __ballot(pre) != 0 && (int)__popcll(need) < KP.prim_min;
+            // the waves of a workgroup that streams its table scan in step: they skip together or not at all
+            // (a wave without any ray goes along with either)
+            if (SRC == SRC_MFMA_STREAMED) skip_scan = __syncthreads_and(skip_scan || __ballot(active) == 0);
             if (skip_scan) active = pre;
         }
 
@@ -556,8 +559,14 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
                 pre_id = -2;
             }
         } else if constexpr (SRC == SRC_MFMA_STREAMED) {
-            scan_mfma_streamed<WGT>(lds_tab, KS.mf_table, KP.mf, pt.o, pt.dh, active, tmin, pt.self_id, lane, cq, KS.sph,
-                                    KS.mf_rows, best_t, best_id, sec);
+            if (!skip_scan)
+                scan_mfma_streamed<WGT>(lds_tab, KS.mf_table, KP.mf, pt.o, pt.dh, active && !pre, tmin, pt.self_id, lane, cq,
+                                        KS.sph, KS.mf_rows, best_t, best_id, sec);
+            if (pre) {
+                best_t = pre_t;
+                best_id = pre_id;
+                pre_id = -2;
+            }
         } else {
             // the whole wave scans: a lane without a ray passes no filter
             rk.thr = active ? rk.thr : __builtin_inff();
@@ -1417,6 +1426,7 @@ struct rt_ctx {
     int mf_resident_full = 0; // the same for the general kernel's variant (0: its table does not fit, or no such device)
     bool mf_full_streamed_ok = true;
     int prim_min = 64; // primary-ray lists of the sphere-only matrix-core kernel: lanes that must need a scan for one to run (0: off; tuning: RT_AMD_PRIM_MIN)
+    int prim_min_streamed = 64; // the same for the variants that stream their table (their workgroups decide as one)
     int last_variant = -1; // sphere source of the last render launch, + 8 for the general kernel
     int mf_streamed_full = 0; // the same for the general kernel's variant with the table streamed through LDS
     unsigned char *d_queue = nullptr; // ring of work-item counters of the persistent render kernel
@@ -1680,7 +1690,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
     // where the scan takes sphere data from: scalar loads (default, fastest measured) or LDS
     // broadcast reads ("lds": resident copy for small scenes, streamed tiles for large ones)
     if (const char *t = getenv("RT_AMD_MF_FULL_MIN")) { int v = atoi(t); if (v >= MF_MIN_SPHERES) ctx->mf_full_min = v; }
-    if (const char *t = getenv("RT_AMD_PRIM_MIN")) { int v = atoi(t); if (*t >= '0' && *t <= '9' && v <= 64) ctx->prim_min = v; }
+    if (const char *t = getenv("RT_AMD_PRIM_MIN")) { int v = atoi(t); if (*t >= '0' && *t <= '9' && v <= 64) ctx->prim_min = ctx->prim_min_streamed = v; }
     if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (*t >= '0' && *t <= '9' && v <= 6) ctx->force_tile = v; }
     const char *src = getenv("RT_AMD_SPHERE_SOURCE");
     ctx->scalar_source = !(src && strcmp(src, "lds") == 0);
@@ -2224,7 +2234,7 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
     } else {
         memset(&k.mf, 0, sizeof k.mf);
     }
-    k.prim_min = src == SRC_MFMA ? ctx->prim_min : 0;
+    k.prim_min = src == SRC_MFMA ? ctx->prim_min : src == SRC_MFMA_STREAMED ? ctx->prim_min_streamed : 0;
     const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, ctx->count_scans ? (unsigned long long *)(ctx->frame_rays + 1) : nullptr, queue};
     ctx->count_scans = false;
 #define RT_LAUNCH(S, L) hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, ka)
