@@ -5,12 +5,16 @@
 //     strips into small square tiles; a work item is all samples of one tile, and the
 //     waves of a persistent grid pull items from one global counter;
 //   * a lane carries one path.  Every iteration all lanes of a wave scan the whole
-//     sphere list (brute force; sphere words arrive through scalar loads, or from LDS in
-//     the general variant with a short list); spheres that pass the packed filter are
+//     sphere list (brute force; from 16 spheres on through the matrix-core filter of
+//     rt_mfma.h over a table in LDS, else sphere words arrive through scalar loads, or from
+//     LDS in the general variant with a short list); spheres that pass the filter are
 //     queued per wave and decided 64 at a time with every lane busy; then shade and
 //     bounce.  A lane whose path ended adds its radiance to its tile's fixed-point
 //     accumulator in LDS and takes the next (pixel, sample) of the open pool; indices
 //     come from a ballot + prefix count;
+//   * with the matrix-core filter a new sample's primary ray is decided at once against the
+//     few spheres its tile's pyramid of primary rays can meet (listed once per tile), and the
+//     wave scans only when its lanes are full of bounced rays;
 //   * a wave holds two tiles, so lanes freed near the end of one start on the next at
 //     once; a tile whose pool is dry and whose last path has ended is tone-mapped and stored.
 #include <hip/hip_runtime.h>
