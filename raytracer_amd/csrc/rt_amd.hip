@@ -2179,6 +2179,15 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
         const int spp = p->samples_per_pixel;
         int pick = 0;
         while (pick < 6 && ((long long)spp << (shapes[pick][0] + shapes[pick][1])) < RT_ITEM_SAMPLES) ++pick;
+        // a frame of very many items takes larger ones while every wave still gets 256 of them: an item costs a
+        // pass over the sphere list for its primary rays (4K, 1000 samples per pixel, 2 / 4 / 8 / 16 / 32 pixels per
+        // item: 367.9 / 358.7 / 355.4 / 356.0 / 357.8 ms; 10 001 spheres, 256 per pixel, 4 / 8 / 16: 3.80 / 3.75 / 3.76 s)
+        const long long waves = (long long)ctx->n_cus * 16;
+        auto items_at = [&](int s) {
+            const int tw = 1 << shapes[s][0], th = 1 << shapes[s][1];
+            return (long long)nstrips * ((p->width + tw - 1) / tw) * (RT_STRIP_ROWS / th);
+        };
+        while (pick < 6 && items_at(pick) >= 256 * waves) ++pick;
         if (ctx->force_tile >= 0) pick = ctx->force_tile;
         k.tile_w_log2 = shapes[pick][0];
         k.tile_h_log2 = shapes[pick][1];
