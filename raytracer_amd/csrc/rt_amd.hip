@@ -343,11 +343,12 @@ __device__ __forceinline__ Tile decode_item(const P &p, unsigned item) {
 }
 
 // The spheres a tile's primary rays can meet (Camera::genRay, src/Camera.cpp:124-135: every ray starts at the camera
-// centre and passes through the tile's patch of the viewport), by a cone around the pyramid those rays fill: axis
-// through the patch's middle, opening angle that of its farthest corner plus 2 %.  A sphere is listed when its
-// centre lies within |r| (plus 0.1 % and 10^-4 of its distance) of the cone, or when the camera is inside it.  The
-// test errs towards listing; what is listed is decided exactly.  Whole wave; returns the length of the list, or -1
-// when it would be longer than PRIM_LIST_CAP (the tile's primary rays then take the scan).
+// centre and passes through the tile's patch of the viewport): those rays fill a pyramid with its apex at the camera,
+// and a sphere that meets it has its centre within |r| of the inner side of each of the pyramid's four side planes.
+// A sphere is listed when that holds with |r| + 0.1 % + 10^-4 of its (L1) distance from the camera; one that contains
+// the camera always does.  The test errs towards listing (a NaN passes); what is listed is decided exactly.
+// Whole wave; returns the length of the list, or -1 when it would be longer than PRIM_LIST_CAP (the tile's primary
+// rays then take the scan).
 template <class P>
 __device__ __forceinline__ int list_primary_candidates(const P &p, const Tile &t, const float4 *__restrict__ sph, int n,
                                                        int *list, int lane) {
@@ -356,14 +357,24 @@ __device__ __forceinline__ int list_primary_candidates(const P &p, const Tile &t
     const float fx0 = (float)t.x0 * p.inv_w, fx1 = (float)(t.x0 + t.vw) * p.inv_w;
     const float fy0 = (float)t.y0 * p.inv_h, fy1 = (float)(t.y0 + t.vh) * p.inv_h;
     const V3 base = ul - c;
-    const V3 q00 = normalized(madd(madd(base, right, fx0), down, fy0)), q10 = normalized(madd(madd(base, right, fx1), down, fy0));
-    const V3 q01 = normalized(madd(madd(base, right, fx0), down, fy1)), q11 = normalized(madd(madd(base, right, fx1), down, fy1));
-    const V3 axis = normalized(q00 + q10 + q01 + q11);
-    const float cmin = fminf(fminf(dot(q00, axis), dot(q10, axis)), fminf(dot(q01, axis), dot(q11, axis)));
-    const float sin_t = sqrtf(fmaxf(1.0f - cmin * cmin, 0.0f)) * 1.02f + 1.0e-6f;
-    // a pyramid wider than a quarter turn (or a degenerate camera) gets no list
-    if (!(cmin > 0.0f) || !(sin_t < 0.7f)) return -1;
-    const float cos_t = sqrtf(1.0f - sin_t * sin_t);
+    // outward unit normals of the four side planes: each holds the apex and one edge line of the patch, i.e. the
+    // edge's direction (down or right) and any vector from the apex to the line -- two vectors at about a right
+    // angle, so the cross product is well conditioned however thin the pyramid is (two neighbouring corner
+    // directions would be nearly parallel); the side a normal must point to is known by construction
+    V3 nrm[4] = {cross(down, madd(base, right, fx0)), cross(down, madd(base, right, fx1)),
+                 cross(right, madd(base, down, fy0)), cross(right, madd(base, down, fy1))};
+    const V3 out[4] = {right * -1.0f, right, down * -1.0f, down};
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float l2 = dot(nrm[k], nrm[k]);
+        ok = ok && l2 > 0.0f && l2 < __builtin_inff();
+        nrm[k] = nrm[k] * __frsqrt_rn(l2);
+        const float side = dot(nrm[k], out[k]);
+        ok = ok && side != 0.0f;
+        if (side < 0.0f) nrm[k] = nrm[k] * -1.0f;
+    }
+    if (!ok) return -1; // a degenerate camera gets no list
     int count = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
@@ -371,12 +382,9 @@ __device__ __forceinline__ int list_primary_candidates(const P &p, const Tile &t
         if (i < n) {
             const float4 sp = sph[i];
             const V3 v = mk(sp.x - c.x, sp.y - c.y, sp.z - c.z);
-            const float along = dot(v, axis), d2 = dot(v, v);
-            const float perp = sqrtf(fmaxf(d2 - along * along, 0.0f));
-            const float dist = sqrtf(d2);
-            const float reach = fabsf(sp.w) * 1.001f + 1.0e-4f * dist;
-            // anything not provably outside is listed: a NaN fails the comparison and passes
-            pass = !(perp * cos_t - along * sin_t > reach) || !(dist > reach);
+            const float reach = fabsf(sp.w) * 1.001f + 1.0e-4f * (fabsf(v.x) + fabsf(v.y) + fabsf(v.z));
+            // anything not provably outside is listed: a NaN fails the comparisons and passes
+            pass = !(dot(v, nrm[0]) > reach) && !(dot(v, nrm[1]) > reach) && !(dot(v, nrm[2]) > reach) && !(dot(v, nrm[3]) > reach);
         }
         const unsigned long long m = __ballot(pass);
         if (pass) {

@@ -22,6 +22,9 @@ __host__ __device__ __forceinline__ V3 madd(V3 a, V3 b, float s) {
     return mk(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z));
 }
 __device__ __forceinline__ V3 normalized(V3 a) { return a * __frsqrt_rn(dot(a, a)); }
+__host__ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
 
 // Scene data never changes while a kernel runs.  Reading it through the constant address space tells
 // the compiler so: wherever the address is the same in every lane (loops over the primitive list, the

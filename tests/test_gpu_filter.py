@@ -416,7 +416,7 @@ def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatc
     assert len(np.unique(a[0][:, :, :3].reshape(-1, 3), axis=0)) > 50, n
 
 
-@pytest.mark.parametrize("case", ["c3_small", "few_samples", "one_pixel_tiles", "inside", "behind", "wide"])
+@pytest.mark.parametrize("case", ["c3_small", "few_samples", "one_pixel_tiles", "inside", "behind", "wide", "thin", "thin8"])
 def test_primary_ray_lists_change_no_byte(case, monkeypatch):
     """The sphere-only matrix-core kernel decides a new sample's primary ray (Camera::genRay, reference
     src/Camera.cpp:124-135: from the camera centre through the pixel) against the spheres its tile's pyramid can meet,
@@ -433,8 +433,11 @@ def test_primary_ray_lists_change_no_byte(case, monkeypatch):
         scene.camera = scenes.make_camera((0.0, 1.0, 0.0), (1.0, -0.1, 0.3))
     elif case == "behind":         # most of the scene behind the camera
         scene.camera = scenes.make_camera((3.0, 0.6, 1.0), (1.0, 0.05, 0.2))
-    elif case == "wide":           # a low frame of coarse pixels: every tile's list is too long, all rays take the scan
-        W, H = 400, 16
+    elif case in ("thin", "thin8"):  # 1x1- and 4x2-pixel tiles of a 4K frame: pyramids 10^-4 rad across, where the cosine
+        W, H, spp = 3840, 2160, 6    # of the opening angle rounds to 1 and neighbouring corner directions are parallel in float
+        monkeypatch.setenv("RT_AMD_TILE", "0" if case == "thin" else "3")
+    elif case == "wide":           # a low frame of very coarse pixels: most tiles' lists are too long, their rays take the scan
+        W, H = 96, 4
     p = RenderParams(W, H, spp, depth, seed=21)
     with Renderer(0) as r:
         r.set_scene(scene)
@@ -451,4 +454,4 @@ def test_primary_ray_lists_change_no_byte(case, monkeypatch):
     primaries = W * H * spp
     print(f"{case}: rays {a[2]} ({primaries} primary), scans {scans_with} with lists, {scans_without} without")
     assert 64 * scans_without >= a[2] and 64 * scans_with >= a[2] - primaries
-    assert scans_with == scans_without if case == "wide" else scans_with < 0.8 * scans_without
+    assert scans_with <= scans_without if case == "wide" else scans_with < 0.8 * scans_without
