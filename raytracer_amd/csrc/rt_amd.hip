@@ -1438,7 +1438,8 @@ struct rt_ctx {
     int mf_resident_full = 0; // the same for the general kernel's variant (0: its table does not fit, or no such device)
     bool mf_full_streamed_ok = true;
     int prim_min = 64; // primary-ray lists of the sphere-only matrix-core kernel: lanes that must need a scan for one to run (0: off; tuning: RT_AMD_PRIM_MIN)
-    int prim_min_streamed = 64; // the same for the variants that stream their table (their workgroups decide as one)
+    int prim_min_full = 48; // the general kernel's paths are longer, fewer lanes start a sample per turn: it scans sooner (485 spheres on a floor plane 8.23 / 7.58 / 7.14 / 7.35 ms at 0 / 32 / 48 / 64; with two lights 15.1 / 15.0 / 15.0 / 15.9)
+    int prim_min_streamed = 64; // the same for the variants that stream their table (their workgroups decide as one; lit cloud of 5000 spheres through the general kernel: 42.0 / 39.7 / 38.4 ms at 0 / 48 / 64)
     int last_variant = -1; // sphere source of the last render launch, + 8 for the general kernel
     int mf_streamed_full = 0; // the same for the general kernel's variant with the table streamed through LDS
     unsigned char *d_queue = nullptr; // ring of work-item counters of the persistent render kernel
@@ -1702,7 +1703,7 @@ RT_API int rt_create(int device, rt_ctx **out) {
     // where the scan takes sphere data from: scalar loads (default, fastest measured) or LDS
     // broadcast reads ("lds": resident copy for small scenes, streamed tiles for large ones)
     if (const char *t = getenv("RT_AMD_MF_FULL_MIN")) { int v = atoi(t); if (v >= MF_MIN_SPHERES) ctx->mf_full_min = v; }
-    if (const char *t = getenv("RT_AMD_PRIM_MIN")) { int v = atoi(t); if (*t >= '0' && *t <= '9' && v <= 64) ctx->prim_min = ctx->prim_min_streamed = v; }
+    if (const char *t = getenv("RT_AMD_PRIM_MIN")) { int v = atoi(t); if (*t >= '0' && *t <= '9' && v <= 64) ctx->prim_min = ctx->prim_min_full = ctx->prim_min_streamed = v; }
     if (const char *t = getenv("RT_AMD_TILE")) { int v = atoi(t); if (*t >= '0' && *t <= '9' && v <= 6) ctx->force_tile = v; }
     const char *src = getenv("RT_AMD_SPHERE_SOURCE");
     ctx->scalar_source = !(src && strcmp(src, "lds") == 0);
@@ -2255,7 +2256,7 @@ int render_impl(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, ui
     } else {
         memset(&k.mf, 0, sizeof k.mf);
     }
-    k.prim_min = src == SRC_MFMA ? ctx->prim_min : src == SRC_MFMA_STREAMED ? ctx->prim_min_streamed : 0;
+    k.prim_min = src == SRC_MFMA ? (full ? ctx->prim_min_full : ctx->prim_min) : src == SRC_MFMA_STREAMED ? ctx->prim_min_streamed : 0;
     const KArgs ka = {k, sc, o_rgba, o_acc, o_rays, ctx->count_scans ? (unsigned long long *)(ctx->frame_rays + 1) : nullptr, queue};
     ctx->count_scans = false;
 #define RT_LAUNCH(S, L) hipLaunchKernelGGL((render_kernel<S, L>), grid, block, lds, st, ka)
