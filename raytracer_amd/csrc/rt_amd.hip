@@ -527,7 +527,8 @@ __global__ __launch_bounds__(wg_threads_of(SRC, FULL), is_mfma(SRC) ? (FULL ? 3 
         bool skip_scan = false;
         if (PRIM && KP.prim_min > 0) {
             const unsigned long long need = __ballot(active && !pre);
-            skip_scan = __ballot(pre) != 0 && (int)__popcll(need) < KP.prim_min;
+            // (and a wave none of whose lanes holds a ray to scan for -- the first turn, the last ones -- runs no scan)
+            skip_scan = need == 0 || (__ballot(pre) != 0 && (int)__popcll(need) < KP.prim_min);
             // the waves of a workgroup that streams its table scan in step: they skip together or not at all
             // (a wave without any ray goes along with either)
             if (SRC == SRC_MFMA_STREAMED) skip_scan = __syncthreads_and(skip_scan || __ballot(active) == 0);

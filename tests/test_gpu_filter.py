@@ -416,7 +416,7 @@ def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatc
     assert len(np.unique(a[0][:, :, :3].reshape(-1, 3), axis=0)) > 50, n
 
 
-@pytest.mark.parametrize("case", ["c3_small", "few_samples", "one_pixel_tiles", "inside", "behind", "wide", "thin", "thin8"])
+@pytest.mark.parametrize("case", ["c3_small", "few_samples", "one_pixel_tiles", "inside", "behind", "wide", "thin", "thin8", "depth1", "depth0"])
 def test_primary_ray_lists_change_no_byte(case, monkeypatch):
     """The sphere-only matrix-core kernel decides a new sample's primary ray (Camera::genRay, reference
     src/Camera.cpp:124-135: from the camera centre through the pixel) against the spheres its tile's pyramid can meet,
@@ -436,6 +436,10 @@ def test_primary_ray_lists_change_no_byte(case, monkeypatch):
     elif case in ("thin", "thin8"):  # 1x1- and 4x2-pixel tiles of a 4K frame: pyramids 10^-4 rad across, where the cosine
         W, H, spp = 3840, 2160, 6    # of the opening angle rounds to 1 and neighbouring corner directions are parallel in float
         monkeypatch.setenv("RT_AMD_TILE", "0" if case == "thin" else "3")
+    elif case == "depth1":         # primary rays only: with lists hardly a scan (tiles whose list is too long)
+        depth = 1
+    elif case == "depth0":         # no ray at all (the reference returns black at depth 0, src/Camera.cpp:138)
+        depth = 0
     elif case == "wide":           # a low frame of very coarse pixels: most tiles' lists are too long, their rays take the scan
         W, H = 96, 4
     p = RenderParams(W, H, spp, depth, seed=21)
@@ -454,4 +458,8 @@ def test_primary_ray_lists_change_no_byte(case, monkeypatch):
     primaries = W * H * spp
     print(f"{case}: rays {a[2]} ({primaries} primary), scans {scans_with} with lists, {scans_without} without")
     assert 64 * scans_without >= a[2] and 64 * scans_with >= a[2] - primaries
-    assert scans_with <= scans_without if case == "wide" else scans_with < 0.8 * scans_without
+    if case == "depth1":
+        assert a[2] == primaries and scans_with < 0.1 * scans_without
+    elif case == "depth0":
+        assert a[2] == 0 and not a[0][:, :, :3].any()
+    assert scans_with <= scans_without if case in ("wide", "depth0") else scans_with < 0.8 * scans_without
