@@ -186,6 +186,10 @@ class Job:
                 "flop_model": f"matrix: scans*64 lanes*{FLOP_PER_ROW_MFMA}*{rows} table rows; algorithmic: "
                               f"rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}); rays/launch={rays_per_launch:.0f}, scans/launch={scans}",
                 "scanned_ray_share": round(scans * 64 / max(rays_per_launch, 1), 4),
+                # primary rays are decided from their tile's list of spheres and take no scan, so a frame needs fewer
+                # matrix products than rays x rows: `frac` is how busy the matrix pipe is kept, the algorithmic
+                # rate is the throughput on the reference's every-ray-against-every-sphere formulation
+                "note": "frac prices the products issued (scans x 64 lanes x rows); rays decided without a scan lower it and raise algorithmic_tflops",
             }
         return {
             "bound": "valu_fp32",
