@@ -14,13 +14,19 @@ Workloads (the benchmark configurations c2..c5):
   c2  small scene 1920x1080, 100 spp, depth 50
   c5  10k-sphere grid scene 3840x2160, 256 spp, depth 50
 
-Launch: python bench.py --gpus 1, or under torch.distributed.run for N > 1.
+Launch: python bench.py --gpus N.  For N > 1 without a launcher (no WORLD_SIZE in the environment) this
+process starts the N ranks itself, as a child `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+before it touches a GPU, passes the child's output through and exits with its code; started under
+torch.distributed.run it is one of the ranks.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -68,31 +74,54 @@ def cpu_baseline(scene, cfg, seconds_target=15.0):
     }
 
 
-def committed_traffic(workload, args, world):
-    """HBM bytes per launch of render_kernel for `workload` at one GPU, from the separate rocprofv3
-    --pmc passes whose summaries are committed under profiles/ (FETCH_SIZE and WRITE_SIZE cannot be
-    read from inside this process).  FETCH_SIZE is doubled as the gfx950 counter tallies 128-byte
-    requests at 64; both counters report KiB.  None when no summary of this workload exists."""
+def committed_summary(workload, args, world):
+    """The newest committed rocprofv3 summary of `workload` at one GPU (profiles/rNN/<workload>_summary.json), or
+    (None, None): counters cannot be read from inside this process, so the figures that come from them are taken
+    from the profile of the same command."""
     if args.spp or world != 1:
         return None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    rounds = sorted(d for d in os.listdir(os.path.join(here, "profiles")) if d.startswith("r")) \
-        if os.path.isdir(os.path.join(here, "profiles")) else []
-    for r in reversed(rounds):
+    if not os.path.isdir(os.path.join(here, "profiles")):
+        return None, None
+    for r in sorted((d for d in os.listdir(os.path.join(here, "profiles")) if d.startswith("r")), reverse=True):
         f = os.path.join(here, "profiles", r, f"{workload}_summary.json")
         if os.path.exists(f):
             try:
-                d = json.load(open(f))
-                return int((2 * d["fetch"]["FETCH_SIZE"] + d["write"]["WRITE_SIZE"]) * 1024), f"profiles/{r}/{workload}_summary.json"
-            except (KeyError, ValueError):
+                return json.load(open(f)), f"profiles/{r}/{workload}_summary.json"
+            except ValueError:
                 return None, None
     return None, None
+
+
+def committed_busy(workload, args, world):
+    """Shares of the kernel's shader cycles in which a SIMD's vector issue port (SQ_ACTIVE_INST_VALU x 4 cycles)
+    and its matrix pipe (SQ_VALU_MFMA_BUSY_CYCLES) were busy, per SIMD (1024 of them), from the committed
+    profile of the workload.  (None, None, None) without one."""
+    d, src = committed_summary(workload, args, world)
+    try:
+        cycles = d["valu"]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+        issue = 4.0 * d["valu"]["SQ_ACTIVE_INST_VALU"] / cycles
+        mfma = d["mfma"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["mfma"]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        return round(issue, 4), round(mfma, 4), src
+    except (KeyError, TypeError, ZeroDivisionError):
+        return None, None, None
+
+
+def committed_traffic(workload, args, world):
+    """HBM bytes per launch of render_kernel for `workload` at one GPU, from the separate rocprofv3
+    --pmc passes whose summaries are committed under profiles/.  FETCH_SIZE is doubled as the gfx950 counter
+    tallies 128-byte requests at 64; both counters report KiB.  None when no summary of this workload exists."""
+    d, src = committed_summary(workload, args, world)
+    try:
+        return int((2 * d["fetch"]["FETCH_SIZE"] + d["write"]["WRITE_SIZE"]) * 1024), src
+    except (KeyError, TypeError):
+        return None, None
 
 
 class Job:
     """One workload set up on this rank: scene resident, strip buffers and gather ready."""
 
-    def __init__(self, name, args, rank, world, local_rank, dev, with_accum):
+    def __init__(self, name, args, rank, world, local_rank, dev, with_accum, ctx_env=None):
         import torch
         from raytracer_amd import Renderer, RenderParams, scenes
         from raytracer_amd.multi_gpu import StripGather
@@ -104,7 +133,17 @@ class Job:
         self.name, self.world, self.rank = name, world, rank
         self.W, self.H = self.cfg["width"], self.cfg["height"]
         self.scene = scenes.by_name(self.cfg["scene"])
-        self.r = Renderer(local_rank)
+        # tuning switches are read from the environment when a context is created
+        saved = {k: os.environ.get(k) for k in (ctx_env or {})}
+        os.environ.update(ctx_env or {})
+        try:
+            self.r = Renderer(local_rank)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         self.r.set_scene(self.scene)
         self.p = RenderParams(self.W, self.H, samples_per_pixel=self.cfg["spp"], max_depth=self.cfg["depth"], seed=0,
                               strip_first=rank, strip_stride=world)
@@ -146,6 +185,13 @@ class Job:
         gath = sum(b.elapsed_time(c) for _, b, c in ev) / steps
         return dt, kern, gath, int(self.rays.item())
 
+    def count_scans(self):
+        """Scans (64 lanes each) of one frame at seed 0, from one more frame rendered through the host entry
+        point outside any timed region."""
+        self.p.seed = 0
+        self.r.render_host(self.p)
+        return self.r.last_scans()
+
     def roofline(self, kern_ms, rays_per_launch, args):
         n_s = self.scene.n_spheres
         achieved = rays_per_launch * (FLOP_PER_TEST * n_s + FLOP_PER_RAY) / (kern_ms * 1e-3) / 1e12
@@ -153,27 +199,27 @@ class Job:
         traffic, traffic_src = committed_traffic(self.name, args, self.world)
         info = self.r.filter_describe()
         if info["in_use"]:
-            # The sphere filter runs on the matrix cores (split-f16 bilinear form): the roofline of the
-            # arithmetic is the dense f16 MFMA peak, priced at the products the kernel really issues for the
-            # rays it traced.  The algorithmic rate of the reference's fp32 formulation is given beside it, with
-            # the FP32 vector peak that bounded the packed-FP32 form of the same filter.
-            # what the matrix pipe was given: scans x 64 lanes x table rows.  Primary rays decided from their tile's
-            # list take no scan, and a scan is issued for all 64 lanes of its wave whether or not each holds a ray.
-            # The count comes from one more frame rendered through the host entry point after the timed region.
+            # The sphere filter runs on the matrix cores (split-f16 bilinear form).  `achieved` prices the
+            # products the kernel really issues against the dense f16 MFMA peak: scans x 64 lanes x table rows
+            # x 64 FLOP (primary rays decided from their tile's list take no scan; a scan is issued for all 64
+            # lanes of its wave).  What BOUNDS the kernel is named by `bound`: the busier of the SIMD's vector
+            # issue port and its matrix pipe in the committed counter profile of this workload.
             rows = info.get("table_rows") or info["n_rows"]
-            self.p.seed = 0
-            self.r.render_host(self.p)
-            scans = self.r.last_scans()
+            scans = self.count_scans()
             mfma = scans * 64 * FLOP_PER_ROW_MFMA * rows / (kern_ms * 1e-3) / 1e12
+            issue_busy, mfma_busy, busy_src = committed_busy(self.name, args, self.world)
+            bound = "mfma" if issue_busy is None or mfma_busy >= issue_busy else "valu_issue"
             return {
-                "bound": "mfma",
+                "bound": bound,
                 "achieved": round(mfma, 3),
                 "peak": PEAK_MFMA_F16_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(mfma / PEAK_MFMA_F16_TFLOPS, 4),
-                # `achieved` counts the products the matrix pipe is given (K = 32 per ray and table row: each of the
-                # 11 terms of the form as hi*hi + hi*lo + lo*hi, rows padded to blocks of 32); the same launch at the
-                # reference formulation's 17 FLOP per ray-sphere test follows, against both peaks
+                # shares of the kernel's cycles in which each SIMD's vector issue port / matrix pipe was busy
+                # (rocprofv3 --pmc passes of this same command, committed; null at N > 1 or other sample counts)
+                "issue_busy": issue_busy,
+                "mfma_busy": mfma_busy,
+                "busy_source": busy_src,
                 "achieved_counts": "matrix products issued",
                 "algorithmic_tflops": round(achieved, 3),
                 "algorithmic_over_mfma_peak": round(achieved / PEAK_MFMA_F16_TFLOPS, 4),
@@ -186,10 +232,9 @@ class Job:
                 "flop_model": f"matrix: scans*64 lanes*{FLOP_PER_ROW_MFMA}*{rows} table rows; algorithmic: "
                               f"rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}); rays/launch={rays_per_launch:.0f}, scans/launch={scans}",
                 "scanned_ray_share": round(scans * 64 / max(rays_per_launch, 1), 4),
-                # primary rays are decided from their tile's list of spheres and take no scan, so a frame needs fewer
-                # matrix products than rays x rows: `frac` is how busy the matrix pipe is kept, the algorithmic
-                # rate is the throughput on the reference's every-ray-against-every-sphere formulation
-                "note": "frac prices the products issued (scans x 64 lanes x rows); rays decided without a scan lower it and raise algorithmic_tflops",
+                "note": "frac prices the matrix products issued (scans x 64 lanes x rows) against the matrix peak; with "
+                        "bound = valu_issue the headroom is instruction count, not frac; brute_force is the same frame "
+                        "with every ray scanned against every sphere",
             }
         return {
             "bound": "valu_fp32",
@@ -207,13 +252,40 @@ class Job:
                           f"rays*({FLOP_PER_TEST_EXECUTED}*{n_s}+{FLOP_PER_RAY}); rays/launch={rays_per_launch:.0f}",
         }
 
+    def brute_force(self, steps, sync):
+        """The same frame with the primary-ray lists off (every ray takes a scan against every table row, the
+        brute-force formulation of SceneManager::hitClosest), timed like the headline: what BASELINE's
+        FLOP convention can be checked against."""
+        info = self.r.filter_describe()
+        if not info["in_use"]:
+            return None
+        rows = info.get("table_rows") or info["n_rows"]
+        sdt, skern, _, srays = self.run(steps, 1, sync)
+        scans = self.count_scans()
+        n_s = self.scene.n_spheres
+        products = scans * 64 * FLOP_PER_ROW_MFMA * rows
+        alg = srays / steps * (FLOP_PER_TEST * n_s + FLOP_PER_RAY)
+        return {
+            "switch": "RT_AMD_PRIM_MIN=0",
+            "value": round(self.W * self.H * self.cfg["spp"] * steps / sdt / 1e6, 3),
+            "unit": "Msamples/s",
+            "ms_per_step": round(sdt / steps * 1e3, 3),
+            "kernel_ms": round(skern, 3),
+            "scans_per_launch": scans,
+            "scanned_ray_share": round(scans * 64 / max(srays / steps, 1), 4),
+            "products_flop": products,
+            "frac": round(products / (skern * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS, 4),
+            "algorithmic_tflops": round(alg / (skern * 1e-3) / 1e12, 3),
+            "algorithmic_over_fp32_valu_peak": round(alg / (skern * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+        }
+
     def describe(self):
         c = self.cfg
         return (f"{self.name}: {c['scene']} scene ({self.scene.n_spheres} spheres) {self.W}x{self.H}, {c['spp']} spp, "
                 f"depth {c['depth']}, samplesPerScatter 1, no lights")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -222,11 +294,32 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline)")
     ap.add_argument("--accum", action="store_true", help="also write the 16 B/px radiance sums")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the c3 figure of the default N = 1 line")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the c3 figure and the lists-off (brute-force) figure of the default N = 1 line")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearse the N > 1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """--gpus N > 1 called plainly: start the N ranks as a fresh child process (one per GPU, RCCL rendezvous on
+    127.0.0.1) and hand its exit code back.  Nothing here has touched a GPU or imported torch: the ranks are
+    started before any GPU call, and this process is never replaced."""
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -235,13 +328,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.share_gpu:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank} has no GPU of its own ({torch.cuda.device_count()} visible); "
+                         f"--share-gpu rehearses N > 1 on one GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -262,13 +356,21 @@ def main():
 
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
     hi = torch.tensor([dt, kern_ms, gather_ms], dtype=torch.float64, device=red_dev)
-    lo = torch.tensor([kern_ms, gather_ms], dtype=torch.float64, device=red_dev)
+    mine = torch.tensor([kern_ms, gather_ms], dtype=torch.float64, device=red_dev)
     rays_total = torch.tensor([my_rays], dtype=torch.int64, device=red_dev)
+    every = [mine]
     if world > 1:
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
     dt = float(hi[0])
+    every = [[float(v[0]), float(v[1])] for v in every]
+
+    # one more frame at seed 0, outside the timed region: its hash is the same for every N (the strip deal changes
+    # no byte), so the N = 1, 2, 4, 8 lines can be checked against each other
+    frame = job.step(0)
+    sync()
 
     if rank == 0:
         cfg = job.cfg
@@ -294,16 +396,22 @@ def main():
             # per-rank means over the timed steps: the spread of kernel_ms is the load balance of the
             # strip deal, gather_ms the cost of assembling the frame on rank 0
             "per_rank": {
-                "kernel_ms_min": round(float(lo[0]), 3), "kernel_ms_max": round(float(hi[1]), 3),
-                "gather_ms_min": round(float(lo[1]), 3), "gather_ms_max": round(float(hi[2]), 3),
+                "kernel_ms_min": round(min(k for k, _ in every), 3), "kernel_ms_max": round(max(k for k, _ in every), 3),
+                "gather_ms_min": round(min(g for _, g in every), 3), "gather_ms_max": round(max(g for _, g in every), 3),
+                "kernel_ms": [round(k, 3) for k, _ in every],
+                "gather_ms": [round(g, 3) for _, g in every],
             },
+            "frame_sha256_seed0": hashlib.sha256(frame.cpu().numpy().tobytes()).hexdigest()[:16],
             # dominant kernel: render_kernel on this rank; algorithmic FLOPs of one launch / its duration
             "roofline": job.roofline(kern_ms, my_rays / args.steps, args),
         }
         if world == 1 and args.workload == "c4" and not args.spp and not args.no_secondary:
+            bf = Job(args.workload, args, rank, world, local_rank, dev, args.accum, ctx_env={"RT_AMD_PRIM_MIN": "0"})
+            out["roofline"]["brute_force"] = bf.brute_force(max(min(args.steps, 3), 1), sync)
+            del bf
             sec = Job("c3", args, rank, world, local_rank, dev, args.accum)
-            sdt, skern, _, srays = sec.run(max(args.steps, 5), 1, sync)
             n = max(args.steps, 5)
+            sdt, skern, _, srays = sec.run(n, 1, sync)
             out["c3"] = {
                 "workload": sec.describe(),
                 "value": round(sec.W * sec.H * sec.cfg["spp"] * n / sdt / 1e6, 3),

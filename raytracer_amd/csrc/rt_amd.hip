@@ -37,38 +37,83 @@
 // ---------------------------------------------------------------------------
 
 // The persistent render kernel pulls its work items from a 32-bit counter in device memory.  A launch
-// takes the next of QUEUE_SLOTS counters (256 bytes apart), so renders issued back to back on
-// different streams do not share one.
+// takes one of QUEUE_SLOTS counters (256 bytes apart), so renders issued back to back on different
+// streams do not share one.  Every counter has an event, recorded behind the launch that uses it: a
+// counter is handed out again only once that launch has finished, and a call that finds all of them
+// with launches in flight fails with RT_ERR_STATE instead of resetting a counter under a running kernel.
 constexpr int QUEUE_SLOTS = 16;
 constexpr size_t QUEUE_SLOT_BYTES = 256;
 
 // Counters of rt_render_noalloc: a device array of the code object instead of a hipMalloc'ed buffer.
 // Every GPU holds its own copy at its own address; `scratch` itself is only a host-side handle, the
-// device address comes from hipGetSymbolAddress (scratch_ptr below) and is what kernels and
+// device address comes from hipGetSymbolAddress (scratch_ring below) and is what kernels and
 // hipMemsetAsync receive.
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
 static_assert(RT_NOALLOC_SCRATCH_BYTES == QUEUE_SLOTS * QUEUE_SLOT_BYTES, "scratch holds one ring of work counters");
 
 namespace {
-constexpr int MAX_DEVICES = 64;
-std::mutex g_scratch_mutex;
-unsigned char *g_scratch_ptr[MAX_DEVICES]; // per device: address of its copy of `scratch`, null until looked up
-std::atomic<unsigned> g_scratch_next[MAX_DEVICES];
 
-// Address of `scratch` on `device`, looked up once per device with that device current.
-hipError_t scratch_ptr(int device, unsigned char **out) {
+struct CounterRing {
+    unsigned char *base = nullptr;      // QUEUE_SLOTS counters, QUEUE_SLOT_BYTES apart, in device memory
+    hipEvent_t done[QUEUE_SLOTS] = {};  // recorded behind the last launch that used the counter
+    unsigned next = 0;
+};
+
+// Events of a ring, created once (with the ring's device current).
+hipError_t ring_create_events(CounterRing &r) {
+    for (int i = 0; i < QUEUE_SLOTS; ++i)
+        if (!r.done[i]) {
+            hipError_t e = hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
+void ring_destroy_events(CounterRing &r) {
+    for (int i = 0; i < QUEUE_SLOTS; ++i)
+        if (r.done[i]) {
+            (void)hipEventDestroy(r.done[i]);
+            r.done[i] = nullptr;
+        }
+}
+
+// A counter no launch in flight is using, searched from the one after the last handed out; -1 when every
+// counter's launch is still running.  A stream under graph capture can neither be asked about its events nor
+// record one outside the graph, so `ask` is false there and the ring is used round robin, unchecked.
+int ring_acquire(CounterRing &r, bool ask) {
+    for (int k = 0; k < QUEUE_SLOTS; ++k) {
+        const int i = (int)((r.next + (unsigned)k) % QUEUE_SLOTS);
+        if (!ask || hipEventQuery(r.done[i]) == hipSuccess) {
+            r.next = (unsigned)i + 1u;
+            return i;
+        }
+        (void)hipGetLastError(); // hipErrorNotReady is an answer, not a failure
+    }
+    return -1;
+}
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;               // guards the rings below from hand-out to the event behind the launch
+CounterRing g_scratch_ring[MAX_DEVICES];  // per device: its copy of `scratch`, null until looked up
+
+// The ring in `scratch` on `device`: address looked up and events created once per device, with that
+// device current (at rt_create, so that rt_render_noalloc itself creates nothing).
+hipError_t scratch_ring(int device, CounterRing **out) {
     *out = nullptr;
     if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (!g_scratch_ptr[device]) {
+    CounterRing &r = g_scratch_ring[device];
+    if (!r.base) {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return e;
         void *ptr = nullptr;
         e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
-        g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+        e = ring_create_events(r);
+        if (e != hipSuccess) return e;
+        r.base = static_cast<unsigned char *>(ptr);
     }
-    *out = g_scratch_ptr[device];
+    *out = &r;
     return hipSuccess;
 }
 } // namespace
@@ -82,12 +127,12 @@ hipError_t scratch_ptr(int device, unsigned char **out) {
 RT_API int rt_render_noalloc(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum, uint64_t *d_rays,
                              void *stream) {
     if (!ctx) return RT_ERR_INVALID;
-    if (!ctx->d_scratch) return fail(ctx, RT_ERR_STATE, "rt_render_noalloc: the device's scratch array was not found");
+    if (!ctx->scratch_ring || !ctx->scratch_ring->base)
+        return fail(ctx, RT_ERR_STATE, "rt_render_noalloc: the device's scratch array was not found");
     // the counter is 32 bits wide: a call may cover at most 2^31 - 1 work items (tiles of 1 to 64 pixels)
     if (p && p->width > 0 && p->height > 0 && (long long)p->width * (long long)p->height > 0x7fffffffLL)
         return fail(ctx, RT_ERR_INVALID, "rt_render_noalloc: more work items than the 32-bit counter in scratch holds");
-    const unsigned n = g_scratch_next[ctx->device].fetch_add(1u);
-    unsigned char *slot = ctx->d_scratch + (size_t)(n % QUEUE_SLOTS) * QUEUE_SLOT_BYTES;
-    return render_impl(ctx, p, d_rgba, d_accum, d_rays, stream, reinterpret_cast<unsigned *>(slot));
+    // every context on this GPU shares the ring: one caller at a time from hand-out to the event behind its launch
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    return render_impl(ctx, p, d_rgba, d_accum, d_rays, stream, *ctx->scratch_ring);
 }
-

@@ -113,6 +113,58 @@ def test_renders_in_flight_on_two_streams_do_not_share_a_work_counter():
             hip.hipStreamDestroy(st)
 
 
+def test_a_seventeenth_render_in_flight_is_refused_not_corrupted():
+    """Sixteen work counters per ring, each handed out again only when the launch that used it has finished: of
+    seventeen long renders issued at once on seventeen streams, sixteen come out whole and the seventeenth is
+    either refused with RT_ERR_STATE (nothing launched, nothing written) or, if a counter had come free by then,
+    whole as well.  Never a frame with tiles missing or rendered twice.  Same for rt_render_noalloc's ring."""
+    import ctypes as C
+
+    from raytracer_amd import RtError
+
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    W, H, N = 640, 360, 17  # about 5 ms of GPU each: the first is still running when the last is asked for
+    with Renderer(0) as r:
+        r.set_scene(scenes.by_name("random_spheres"))
+        params = [RenderParams(W, H, samples_per_pixel=512, max_depth=50, seed=100 + i) for i in range(N)]
+        want = [_render(r, p, False)[0] for p in params]  # one at a time
+        streams = [C.c_void_p() for _ in range(N)]
+        for st in streams:
+            assert hip.hipStreamCreate(C.byref(st)) == 0
+        for noalloc in (False, True):
+            bufs = [_DevBuf(hip, W * H * 4) for _ in range(N)]
+            refused = []
+            for i in range(N):
+                try:
+                    r.render_device(params[i], bufs[i], None, None, streams[i].value, noalloc=noalloc)
+                except RtError as e:
+                    assert "(-4)" in str(e) and "in flight" in str(e), str(e)
+                    refused.append(i)
+            assert hip.hipDeviceSynchronize() == 0
+            assert len(refused) <= 1 and all(i == N - 1 for i in refused), refused
+            for i in range(N):
+                got = bufs[i].to_numpy(np.uint8, (H, W, 4))
+                if i in refused:
+                    assert not got.any(), "a refused render wrote pixels"
+                else:
+                    assert np.array_equal(got, want[i]), f"noalloc={noalloc}: frame {i} of {N} in flight differs"
+            # with everything finished the ring is free again
+            r.render_device(params[0], bufs[0], None, None, streams[0].value, noalloc=noalloc)
+            assert hip.hipDeviceSynchronize() == 0
+            assert np.array_equal(bufs[0].to_numpy(np.uint8, (H, W, 4)), want[0])
+            print(f"noalloc={noalloc}: refused {refused}")
+            for b in bufs:
+                b.free()
+        for st in streams:
+            hip.hipStreamDestroy(st)
+
+
 def test_noalloc_rejects_what_it_cannot_count():
     from raytracer_amd import RtError
 
