@@ -257,6 +257,8 @@ enum {
  *   id       : index of the closest sphere or -1;  t: HitRecord::time;
  *   normal   : HitRecord::normal (unit, facing against the ray);
  *   front    : HitRecord::frontFace (0/1).  t/normal/front may be NULL.
+ *   tmin     : any float; with tmin <= 0 roots behind the origin count, as Interval::surrounds
+ *              (inc/RTGeometry.h:79-81) has it.
  * Host-pointer version (copies in and out, synchronous). */
 int rt_first_hit_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir,
                       float tmin, uint32_t flags, int32_t *h_id, float *h_t,

@@ -224,7 +224,7 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (argc < 6) {
-        std::fprintf(stderr, "usage: %s <out.rgba> <W> <H> <spp> <depth> [ppm|-] [scene]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <out.rgba> <W> <H> <spp> <depth> [ppm|-] [scene] [samplesPerScatter]\n", argv[0]);
         return 2;
     }
     const int W = atoi(argv[2]), H = atoi(argv[3]);
@@ -233,7 +233,7 @@ int main(int argc, char **argv) {
     const bool lit = buildScene(argc > 7 ? argv[7] : "small", scene, mm);
     Camera cam; // default pose: centre 0, direction +z
     cam.renderProperties.samplesPerPixel = atoi(argv[4]);
-    cam.renderProperties.samplesPerScatter = 1;
+    cam.renderProperties.samplesPerScatter = argc > 8 ? atoi(argv[8]) : 1; // (the reference's default is 3)
     cam.renderProperties.maxRayDepth = atoi(argv[5]);
     cam.renderProperties.enableLDirect = lit;
     cam.seed = 21;

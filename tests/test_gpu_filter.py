@@ -376,11 +376,11 @@ def test_single_ray_queries_through_the_table(oracle64):
             assert np.allclose(t[oid >= 0], ot[oid >= 0], rtol=1e-4)
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
-def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatch, lit=False):
-    """Random scenes (16 to 3000 spheres, radii over two decades, up to three very large spheres, the camera
-    inside or outside the cloud): the matrix-core filter and the packed filter select the same hits, so frames,
-    radiance sums and ray counts are equal."""
+def random_cloud_case(seed, setenv, lit=False):
+    """One random scene (16 to 3000 spheres, radii over two decades, up to three very large spheres, the camera
+    inside or outside the cloud) rendered with the matrix-core filter and with the packed filter.
+    -> (same, in_view, what): `same`: frames, radiance sums and ray counts are equal; `in_view`: the scene is in
+    view (paths bounce and the frame is not one colour), i.e. the comparison says something."""
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([16, 17, 31, 33, 64, 200, 485, 1000, 1440, 1441, 2000, 3000]))
     rmax = float(rng.uniform(0.1, 1.0))
@@ -405,18 +405,27 @@ def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatc
         r.set_scene(scene)
         assert r.filter_describe()["in_use"]
         a = r.render_host(p, want_accum=True)
-    monkeypatch.setenv("RT_AMD_SPHERE_SOURCE", "scalar")
+    setenv("RT_AMD_SPHERE_SOURCE", "scalar")
     with Renderer(0) as r:
         r.set_scene(scene)
         b = r.render_host(p, want_accum=True)
-    assert a[2] == b[2], f"n={n}: ray counts differ: {a[2]} vs {b[2]}"
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), f"n={n}"
-    # the scene is in view: paths bounce, and the frame is not one colour
-    assert a[2] > 1.003 * p.width * p.height * p.samples_per_pixel, (n, a[2])
-    assert len(np.unique(a[0][:, :, :3].reshape(-1, 3), axis=0)) > 50, n
+    same = a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    in_view = (a[2] > 1.003 * p.width * p.height * p.samples_per_pixel and
+               len(np.unique(a[0][:, :, :3].reshape(-1, 3), axis=0)) > 50)
+    return same, in_view, f"n={n}: rays {a[2]} vs {b[2]}, {int((a[0] != b[0]).sum())} bytes differ"
 
 
-@pytest.mark.parametrize("case", ["c3_small", "few_samples", "one_pixel_tiles", "inside", "behind", "wide", "thin", "thin8", "depth1", "depth0"])
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_clouds_render_the_same_bytes_with_either_filter(seed, monkeypatch):
+    """The matrix-core filter and the packed filter select the same hits, so frames, radiance sums and ray counts
+    of random scenes are equal."""
+    same, in_view, what = random_cloud_case(seed, monkeypatch.setenv)
+    assert same, what
+    assert in_view, f"seed {seed} shows nothing: {what}"
+
+
+@pytest.mark.parametrize("case", ["c3_small", "few_samples", "one_pixel_tiles", "inside", "behind", "wide", "thin", "thin8", "depth1", "depth0",
+                                  "far", "far_thin"])
 def test_primary_ray_lists_change_no_byte(case, monkeypatch):
     """The sphere-only matrix-core kernel decides a new sample's primary ray (Camera::genRay, reference
     src/Camera.cpp:124-135: from the camera centre through the pixel) against the spheres its tile's pyramid can meet,
@@ -442,6 +451,18 @@ def test_primary_ray_lists_change_no_byte(case, monkeypatch):
         depth = 0
     elif case == "wide":           # a low frame of very coarse pixels: most tiles' lists are too long, their rays take the scan
         W, H = 96, 4
+    elif case in ("far", "far_thin"):
+        # scene and camera moved 10^4 away from the origin: a ray's viewport point is rounded at that magnitude
+        # (2 ulp of 10^4 is a 4K pixel and more), the list's side planes are built from the small difference
+        # ul - c; the list's margin must cover the difference or silhouette hits are lost
+        shift = np.array([1.0e4, -2.0e4, 5.0e3], np.float32)
+        for k, ax in enumerate(("cx", "cy", "cz")):
+            scene.spheres[ax] = scene.spheres[ax] + shift[k]
+        c = np.array([13.0, -3.0, 2.0]) + shift.astype(np.float64)
+        scene.camera = scenes.make_camera(c, (-13.0, 3.0, -2.0))
+        if case == "far_thin":
+            W, H, spp = 3840, 2160, 4
+            monkeypatch.setenv("RT_AMD_TILE", "0")
     p = RenderParams(W, H, spp, depth, seed=21)
     with Renderer(0) as r:
         r.set_scene(scene)
@@ -463,3 +484,27 @@ def test_primary_ray_lists_change_no_byte(case, monkeypatch):
     elif case == "depth0":
         assert a[2] == 0 and not a[0][:, :, :3].any()
     assert scans_with <= scans_without if case in ("wide", "depth0") else scans_with < 0.8 * scans_without
+
+
+def test_the_whole_c4_frame_is_the_same_bytes_with_and_without_primary_ray_lists(monkeypatch):
+    """Benchmark configuration c4 (485 spheres, 3840x2160, 1000 samples per pixel, depth 50) in full: primary rays
+    decided from their tile's list (Camera::genRay, reference src/Camera.cpp:124-135) against every ray taking the
+    scan: frame, radiance sums and ray count equal, about half as many scans.  The thin pyramids of 4K tiles are
+    where a too-tight list loses silhouette hits."""
+    scene = scenes.by_name("random_spheres")
+    p = RenderParams(3840, 2160, 1000, 50, seed=0)
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        a = r.render_host(p, want_accum=True)
+        assert r.last_kernel_variant() == 3
+        ms_with, scans_with = r.last_kernel_ms(), r.last_scans()
+    monkeypatch.setenv("RT_AMD_PRIM_MIN", "0")
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        b = r.render_host(p, want_accum=True)
+        ms_without, scans_without = r.last_kernel_ms(), r.last_scans()
+    print(f"c4: {ms_with:.1f} ms with lists ({scans_with} scans), {ms_without:.1f} ms without ({scans_without}), rays {a[2]}")
+    assert a[2] == b[2], f"ray counts differ: {a[2]} vs {b[2]}"
+    assert np.array_equal(a[0], b[0]), f"{int((a[0] != b[0]).sum())} bytes of the frame differ"
+    assert np.array_equal(a[1], b[1]), "radiance sums differ"
+    assert 64 * scans_without >= a[2] and scans_with < 0.6 * scans_without

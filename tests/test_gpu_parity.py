@@ -120,6 +120,38 @@ def test_first_hit_secondary_rays(renderer, oracle64):
     assert np.max(np.abs(t[hit] - ot[hit]) / np.abs(ot[hit])) <= 1e-5
 
 
+@pytest.mark.parametrize("tmin", [-2.5, 0.0])
+def test_first_hit_with_an_interval_that_starts_behind_the_origin(renderer, oracle64, tmin):
+    """hitClosest takes any Interval(tmin, +inf) (reference src/RayTracer.cpp:68-82, inc/RTGeometry.h:79-81): with
+    tmin <= 0 the winner is the smallest root above tmin, negative roots included -- rays that start inside or
+    behind spheres.  The plain query must not order such roots by their bit patterns."""
+    scene = scenes.random_spheres_scene()
+    renderer.set_scene(scene)
+    assert renderer.filter_describe()["in_use"]
+    rng = np.random.default_rng(23)
+    n = 30000
+    k = rng.integers(1, scene.n_spheres, n)
+    c = np.stack([scene.spheres["cx"][k], scene.spheres["cy"][k], scene.spheres["cz"][k]], 1).astype(np.float64)
+    r = np.abs(scene.spheres["r"][k].astype(np.float64))
+    off = rng.normal(size=(n, 3))
+    off /= np.linalg.norm(off, axis=1, keepdims=True)
+    # a third of the origins inside a sphere, a third just behind one, a third a few radii away
+    dist = np.where(np.arange(n) % 3 == 0, 0.5, np.where(np.arange(n) % 3 == 1, 1.3, 4.0))
+    org = (c + off * (r * dist)[:, None]).astype(np.float32)
+    aim = rng.normal(size=(n, 3)) * 0.3 - off  # mostly back through the sphere
+    dirs = (aim * rng.uniform(0.5, 2.0, size=(n, 1))).astype(np.float32)
+    oid, ot, onrm, ofront, margin = oracle64.first_hit(scene, org, dirs, tmin=tmin, want_margin=True)
+    hit = oid >= 0
+    assert (ot[hit] < 0).mean() > 0.2, "the case must hold negative roots"
+    ids, t, nrm, front = renderer.first_hit(org, dirs, tmin=tmin, refine=True)
+    assert np.array_equal(ids, oid)
+    assert np.max(np.abs(t[hit] - ot[hit]) / np.maximum(np.abs(ot[hit]), 1e-3)) <= 1e-5
+    ids, t, nrm, front = renderer.first_hit(org, dirs, tmin=tmin, refine=False)
+    bad = ids != oid
+    assert bad.mean() < 2e-3
+    assert np.all(margin[bad] < 1e-5), f"unambiguous rays disagree: margins {margin[bad]}"
+
+
 def test_first_hit_edge_cases(renderer, oracle64):
     b = scenes._Builder()
     m = b.lambertian((0.5, 0.5, 0.5))

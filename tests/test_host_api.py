@@ -131,6 +131,43 @@ def test_camera_render_matches_oracle(tmp_path, oracle64):
 
 
 @pytest.mark.gpu
+def test_camera_render_with_three_samples_per_scatter(tmp_path, oracle64):
+    """samplesPerScatter = 3 is the reference's default (inc/Camera.h:40): computeMultipleScatterLInderect averages
+    three scattered rays per hit, a tree of 3^depth rays per sample (src/Camera.cpp:180-195).  Camera::render here
+    folds S into S * samplesPerPixel single-scatter samples (same expectation): the frame and the ray count are
+    those of that render byte for byte, and the frame agrees with the oracle's RECURSIVE S = 3 render as well as
+    another seed of that render does."""
+    W, H, k, depth = 64, 36, 16, 6
+    raw3, raw1 = str(tmp_path / "s3.rgba"), str(tmp_path / "s1.rgba")
+    r3 = subprocess.run([_need_demo(), raw3, str(W), str(H), str(k), str(depth), "-", "small", "3"],
+                        capture_output=True, text=True)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    r1 = subprocess.run([_need_demo(), raw1, str(W), str(H), str(3 * k), str(depth), "-", "small", "1"],
+                        capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    img3 = np.fromfile(raw3, np.uint8).reshape(H, W, 4)
+    img1 = np.fromfile(raw1, np.uint8).reshape(H, W, 4)
+    assert np.array_equal(img3, img1)
+    rays3, rays1 = int(r3.stdout.strip().split()[-1]), int(r1.stdout.strip().split()[-1])
+    assert rays3 == rays1 > 0
+    scene = scenes.small_scene()
+    a, _, tree_rays = oracle64.render(scene, W, H, k, depth, seed=21, samples_per_scatter=3, iterative=False)
+    b, _, _ = oracle64.render(scene, W, H, k, depth, seed=22, samples_per_scatter=3, iterative=False)
+    assert tree_rays > 2 * rays3, "the recursive render traces a tree of rays, the folded one a path per sample"
+    mse = lambda x, y: float(np.mean((x[:, :, :3].astype(float) - y[:, :, :3].astype(float)) ** 2))
+    floor = mse(a, b)  # seed-to-seed noise of the recursive render
+    got = mse(img3, b)
+    bias = np.abs((img3[:, :, :3].astype(float) - b[:, :, :3].astype(float)).mean(axis=(0, 1))).max()
+    print(f"S = 3: mse vs the recursive oracle {got:.2f}, its seed-to-seed {floor:.2f}, mean bias {bias:.3f}/255")
+    assert got <= 1.25 * floor
+    assert bias <= 0.4
+    # and the single-scatter oracle of the same seed draws the same words as the folded render
+    same, _, orc_rays = oracle64.render(scene, W, H, 3 * k, depth, seed=21)
+    _assert_same_streams(img3[:, :, :3], same[:, :, :3])
+    assert abs(rays3 - orc_rays) <= 0.004 * orc_rays
+
+
+@pytest.mark.gpu
 def test_camera_render_with_lights_matches_oracle(tmp_path, oracle64):
     """enableLDirect with two Phong lights through the host API (Camera::computeDirectLighting,
     reference src/Camera.cpp:161-178)."""

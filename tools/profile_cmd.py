@@ -113,6 +113,12 @@ def main():
         d["shader_cycles"] = v["GRBM_GUI_ACTIVE"] / 8.0
         d["wave_cycle_split"] = {k: v[k] / v["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")
                                  if k in v}
+        # share of the shader cycles in which a SIMD's vector issue port was taken (an instruction holds it 4 cycles)
+        d["issue_busy"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    f = summary.get("mfma", {})
+    if f.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        d["mfma_busy"] = f["SQ_VALU_MFMA_BUSY_CYCLES"] / (f["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        d["mfma_insts"] = f["SQ_INSTS_MFMA"]
     if m.get("SQ_LDS_IDX_ACTIVE"):
         d["lds_conflict_share"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
         d["lds_busy_share_of_cu_cycles"] = m["SQ_LDS_IDX_ACTIVE"] / (m["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
