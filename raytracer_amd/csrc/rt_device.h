@@ -188,6 +188,8 @@ struct SecClock {
 // tuning build only: wave-level event counters
 __device__ unsigned long long g_stats[8];
 __device__ unsigned long long g_times[8]; // first start, first end, last end, sum of durations, waves, max items
+__device__ unsigned long long g_turns[8]; // turns without a scan, their lanes with a decided primary ray, their lanes waiting
+                                          // for a scan, primaries decided as miss / as hit / left to the scan
 __device__ __forceinline__ void stat(int k) {
     unsigned long long m = __ballot(1);
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&g_stats[k], 1ull);

@@ -50,7 +50,13 @@ constexpr int wg_threads_of(int src, bool full = false) {
     return src == SRC_MFMA ? (full ? RT_MF_FULL_THREADS : 1024)
            : src == SRC_MFMA_STREAMED ? (full ? RT_MF_FULL_THREADS : RT_MF_STREAM_THREADS) : WG_THREADS;
 }
-constexpr int cand_cap_of(int src) { return is_mfma(src) ? 128 : CAND_CAP; }
+// (the streamed variant's waves scan in step, a barrier per table tile, so a wave that stops to decide a batch holds
+// up its workgroup; a queue long enough to leave nearly all decisions to the end of the scan (448 entries) was
+// measured on the 10 001-sphere frame and changed nothing: 3.78 s either way)
+#ifndef RT_MF_STREAM_QUEUE
+#define RT_MF_STREAM_QUEUE 128
+#endif
+constexpr int cand_cap_of(int src) { return src == SRC_MFMA_STREAMED ? RT_MF_STREAM_QUEUE : is_mfma(src) ? 128 : CAND_CAP; }
 constexpr size_t acc_bytes_of(int src, bool full = false) {
     return (size_t)(wg_threads_of(src, full) / 64) * WAVE_LDS_WORDS * sizeof(unsigned long long);
 }

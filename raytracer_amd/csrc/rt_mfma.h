@@ -172,6 +172,9 @@ __device__ __forceinline__ uint32_t gather32(const float16v &acc0, const float16
 // readable block (its content does not matter).
 // Software pipeline: the matrix pipe works on one ray half's tile while the other's is examined, and the
 // table words of the next block are on their way from LDS meanwhile.
+// FLUSH_AT: queue fill from which batches are decided inside the loop (a turn of the recording loop adds up to 64
+// entries, so the queue holds FLUSH_AT + 64).
+template <int FLUSH_AT = 64>
 __device__ __forceinline__ void mfma_scan_blocks(const uint4v *tab_lane, int blk0, int nblk, const RayOperand &op,
                                                  const CandQ &cq, int &count, int lane, V3 o, V3 dh, float tmin,
                                                  int self_id, const float4 *__restrict__ sph, SecClock &sec) {
@@ -210,7 +213,7 @@ __device__ __forceinline__ void mfma_scan_blocks(const uint4v *tab_lane, int blk
                 cq.ent[count + lane_rank(any)] = block_part + (bit << 5);
             }
             count += (int)__popcll(any);
-            if (count >= 64) {
+            if (count >= FLUSH_AT) {
                 sec.mark(10);
                 do resolve_batch(cq, count, 64, lane, o, dh, tmin, self_id, sph);
                 while (count >= 64);
@@ -272,7 +275,7 @@ __device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, 
 #endif
 constexpr int MF_TILE_BLOCKS = RT_MF_TILE_BLOCKS;
 constexpr int MF_TILE_WORDS = (MF_TILE_BLOCKS + 1) * MF_BLOCK_WORDS; // with the block the read-ahead touches
-template <int WG_THREADS_T, class F>
+template <int WG_THREADS_T, int QUEUE_CAP, class F>
 __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *__restrict__ gtab, const F &fr, V3 o, V3 dh,
                                                    bool live, float tmin, int self_id, int lane, const CandQ &cq,
                                                    const float4 *__restrict__ sph, const float4 *__restrict__ rows,
@@ -300,8 +303,8 @@ __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *_
             for (int k = 0; k < PER_THREAD; ++k)
                 if (EVEN || tid + k * WG_THREADS_T < TILE) next[k] = g[tid + k * WG_THREADS_T];
         }
-        mfma_scan_blocks(bufs + (t & 1) * MF_TILE_WORDS + lane, t * MF_TILE_BLOCKS, MF_TILE_BLOCKS, op, cq, count, lane, o, dh,
-                         tmin, self_id, rows, sec);
+        mfma_scan_blocks<QUEUE_CAP - 64>(bufs + (t & 1) * MF_TILE_WORDS + lane, t * MF_TILE_BLOCKS, MF_TILE_BLOCKS, op, cq, count,
+                                         lane, o, dh, tmin, self_id, rows, sec);
         if (t + 1 < n_tiles) {
             uint4v *dst = bufs + ((t + 1) & 1) * MF_TILE_WORDS;
 #pragma unroll

@@ -5,7 +5,10 @@ import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [("random_spheres", 320, 180, 40, 50), ("random_spheres", 160, 96, 500, 50), ("small", 256, 144, 64, 50),
          ("small_bubble", 200, 120, 16, 10), ("grid10k", 128, 72, 8, 50), ("mixed_selected", 240, 136, 24, 10),
-         ("mixed_lit", 240, 136, 16, 8), ("small_phong", 160, 90, 16, 8), ("halo_overlap", 160, 90, 16, 6)]
+         ("mixed_lit", 240, 136, 16, 8), ("small_phong", 160, 90, 16, 8), ("halo_overlap", 160, 90, 16, 6),
+         # frames whose last tiles are clipped by the image's edge, few and many samples per pixel
+         ("small_bubble", 37, 19, 7, 50), ("random_spheres", 1201, 75, 20, 20), ("random_spheres", 203, 101, 300, 50),
+         ("grid10k", 67, 35, 5, 30)]
 if len(sys.argv) == 4 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
     os.environ["RT_AMD_LIB"] = os.path.abspath(sys.argv[2])

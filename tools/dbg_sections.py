@@ -17,10 +17,13 @@ r.render_host(RenderParams(W, H, spp, depth, flags=flags))
 lib.rt_debug_sections(out, 1)
 _, _, rays = r.render_host(RenderParams(W, H, spp, depth, flags=flags))
 lib.rt_debug_sections(out, 0)
-v = list(out); tot = sum(v)
+v = list(out)
+clock_ghz = 0.1 * v[14] / max(v[15], 1)  # shader cycles per tick of the 100 MHz counter, summed over the waves
+v[14] = v[15] = 0
+tot = sum(v)
 names = ["ray set-up + scan", "shade", "accumulate", "store tiles", "hand-out", "rng + raygen/scatter", "-", "outside loop",
          "scan: matrix products + sign masks", "scan: recording candidates", "scan: deciding candidates",
          "scan: big spheres + result", "streamed: first tile + barrier", "streamed: tile barriers", "-", "-"]
-print(f"{name} {W}x{H} {spp} spp: kernel {r.last_kernel_ms():.2f} ms, rays {rays}")
+print(f"{name} {W}x{H} {spp} spp: kernel {r.last_kernel_ms():.2f} ms, rays {rays}, scans {r.last_scans()}, in-kernel shader clock {clock_ghz:.3f} GHz")
 for n, x in zip(names, v):
     if x: print(f"  {n:24s} {100.0 * x / tot:6.2f} % of wave cycles")

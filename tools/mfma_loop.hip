@@ -100,6 +100,76 @@ void run(const uint4v *dtab, int n_blocks, int reps, float *d, unsigned long lon
            ms * 1e6 / blocks, (double)h[nw / 2] / blocks);
 }
 
+// The same work per block (32 table rows x 64 rays, K = 32) as eight v_mfma_f32_16x16x32_f16: one instruction covers the
+// whole K of 16 rows x 16 rays (4 result registers); the table block is two A operands, the rays four B operands.
+typedef float float4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024, 4) void k16(const uint4v *__restrict__ gtab, int n_blocks, int reps, float *out,
+                                               unsigned long long *cyc, float s) {
+    extern __shared__ __attribute__((aligned(16))) uint4v tab[];
+    for (int i = threadIdx.x; i < (n_blocks + 1) * 128; i += 1024) tab[i] = gtab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint4v *tl = tab + lane;
+    half8 b[4];
+    for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < 8; ++j) b[g][j] = (_Float16)(s * (1 + g + j + (g & 1 ? 0 : lane)));
+    unsigned found = 0;
+    const float4v zero = {0, 0, 0, 0};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < reps; ++r) {
+        half8 a0 = __builtin_bit_cast(half8, tl[0]), a1 = __builtin_bit_cast(half8, tl[64]);
+        float4v c[8];
+        c[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[0], zero, 0, 0, 0);
+        c[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[0], zero, 0, 0, 0);
+        c[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[1], zero, 0, 0, 0);
+        c[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[1], zero, 0, 0, 0);
+#pragma unroll 1
+        for (int blk = 0; blk < n_blocks; ++blk) {
+            c[4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[2], zero, 0, 0, 0);
+            c[5] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[2], zero, 0, 0, 0);
+            c[6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[3], zero, 0, 0, 0);
+            c[7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[3], zero, 0, 0, 0);
+            a0 = __builtin_bit_cast(half8, tl[(2 * blk + 2) * 64]);
+            a1 = __builtin_bit_cast(half8, tl[(2 * blk + 3) * 64]);
+            uint32_t any = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) any |= __float_as_uint(c[t][v]);
+            const bool some = __ballot((int)any < 0) != 0;
+            if (some) found++;
+            c[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[0], zero, 0, 0, 0);
+            c[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[0], zero, 0, 0, 0);
+            c[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[1], zero, 0, 0, 0);
+            c[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[1], zero, 0, 0, 0);
+        }
+        asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)found;
+    if (lane == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+
+void run16(const uint4v *dtab, int n_blocks, int reps, float *d, unsigned long long *dc, std::vector<unsigned long long> &h) {
+    const size_t lds = (size_t)(n_blocks + 1) * 2048;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k16, dim3(256), dim3(1024), lds, 0, dtab, n_blocks, 2, d, dc, 1.0f);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k16, dim3(256), dim3(1024), lds, 0, dtab, n_blocks, reps, d, dc, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const size_t nw = 256 * 16;
+    hipMemcpy(h.data(), dc, nw * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.begin() + nw);
+    const double blocks = (double)reps * n_blocks;
+    printf("  %-44s %8.3f ms  = %6.1f ns per block per wave; s_memtime median %7.1f ticks per block per wave\n",
+           "full loop as eight 16x16x32 products", ms, ms * 1e6 / blocks, (double)h[nw / 2] / blocks);
+}
+
 // The streamed form: the loop restarts every 16 blocks (pipeline prologue and one wasted read-ahead tile), with a
 // workgroup barrier per tile, and with the next tile fetched from global memory into registers before the blocks
 // and stored to the other LDS buffer after them.
@@ -185,6 +255,9 @@ int main(int argc, char **argv) {
     std::vector<unsigned long long> h(256 * 16);
     printf("16 waves per CU (4 per SIMD), %d blocks of 32 rows x 64 rays, %d scans per wave\n", n_blocks, reps);
     run<V_FULL>(dtab, n_blocks, reps, d, dc, h);
+    run16(dtab, n_blocks, reps, d, dc, h);
+    run<V_FULL>(dtab, n_blocks, reps, d, dc, h);
+    run16(dtab, n_blocks, reps, d, dc, h);
     run<V_NO_LDS>(dtab, n_blocks, reps, d, dc, h);
     run<V_NO_OR>(dtab, n_blocks, reps, d, dc, h);
     run<V_MFMA_ONLY>(dtab, n_blocks, reps, d, dc, h);
