@@ -13,8 +13,8 @@
  *     never throws; rt_last_error() gives a printable reason.  (The reference
  *     uses assert()/silent clamps only, src/Camera.cpp:76-77.)
  *   - one context per device; a context is not re-entrant (calls on one context come from one
- *     host thread at a time; up to 16 asynchronous renders may be in flight on its streams, a
- *     render asked for while 16 are still running fails with RT_ERR_STATE).
+ *     host thread at a time; renders are asynchronous, any number may be queued on one stream and
+ *     up to 16 may be in flight across streams: one more fails with RT_ERR_STATE).
  *   - plain pointers and sizes only; "d_" arguments are DEVICE pointers valid on
  *     the context's device, "h_" arguments are HOST pointers.
  *   - the library never falls back to a CPU renderer: scenes it cannot render
@@ -195,7 +195,8 @@ int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
  *   d_rays  : device, optional, one uint64 that the call ADDS the number of
  *             closest-hit queries to
  *   stream  : a hipStream_t (NULL = the default stream).  The call is asynchronous.
- * Up to 16 renders of one context may be in flight; one more fails with RT_ERR_STATE and launches nothing.
+ * Any number of renders may be queued on one stream; across streams up to 16 renders of one context may be in
+ * flight, and one more on yet another stream fails with RT_ERR_STATE and launches nothing.
  */
 int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum,
               uint64_t *d_rays, void *stream);
@@ -208,8 +209,9 @@ int rt_render(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum,
  * are the caller's and the context's, set up beforehand as for rt_render().
  * Limits: at most 2^31 - 1 work items per call (width*height < 2^31), rejected with RT_ERR_INVALID
  * beyond that.  All contexts on one GPU share the array's 16 counters; each is handed out again once the
- * launch that used it has finished (an event per counter, created at rt_create): up to 16 calls may be in
- * flight on one GPU, a call beyond that fails with RT_ERR_STATE and launches nothing.  On a stream under
+ * launch that used it has finished (an event per counter, created at rt_create) or to a call on the stream that
+ * launch ran on: any number of calls may be queued on one stream, up to 16 may be in flight on one GPU across
+ * streams, and a call beyond that fails with RT_ERR_STATE and launches nothing.  On a stream under
  * graph capture the events cannot be asked, and the counters are used round robin unchecked. */
 #define RT_NOALLOC_SCRATCH_BYTES 4096
 int rt_render_noalloc(rt_ctx *ctx, const rt_params *p, void *d_rgba, void *d_accum,

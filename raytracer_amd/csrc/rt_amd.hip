@@ -55,7 +55,9 @@ namespace {
 
 struct CounterRing {
     unsigned char *base = nullptr;      // QUEUE_SLOTS counters, QUEUE_SLOT_BYTES apart, in device memory
-    hipEvent_t done[QUEUE_SLOTS] = {};  // recorded behind the last launch that used the counter
+    hipEvent_t done[QUEUE_SLOTS] = {};  // recorded behind the last launch that used the counter ...
+    hipStream_t last[QUEUE_SLOTS] = {}; // ... on this stream
+    bool used[QUEUE_SLOTS] = {};
     unsigned next = 0;
 };
 
@@ -77,19 +79,28 @@ void ring_destroy_events(CounterRing &r) {
         }
 }
 
-// A counter no launch in flight is using, searched from the one after the last handed out; -1 when every
-// counter's launch is still running.  A stream under graph capture can neither be asked about its events nor
+// A counter that the launch about to be issued on `st` may reset, searched from the one after the last handed out:
+// one whose last launch ran on `st` itself (stream order puts the reset behind that launch, however many frames a
+// caller queues on one stream), else one whose last launch has finished; -1 when every counter belongs to a launch
+// still running on another stream.  A stream under graph capture can neither be asked about its events nor
 // record one outside the graph, so `ask` is false there and the ring is used round robin, unchecked.
-int ring_acquire(CounterRing &r, bool ask) {
+int ring_acquire(CounterRing &r, bool ask, hipStream_t st) {
     for (int k = 0; k < QUEUE_SLOTS; ++k) {
         const int i = (int)((r.next + (unsigned)k) % QUEUE_SLOTS);
-        if (!ask || hipEventQuery(r.done[i]) == hipSuccess) {
+        if (!ask || !r.used[i] || r.last[i] == st || hipEventQuery(r.done[i]) == hipSuccess) {
             r.next = (unsigned)i + 1u;
             return i;
         }
         (void)hipGetLastError(); // hipErrorNotReady is an answer, not a failure
     }
     return -1;
+}
+
+// The launch that uses counter `slot` has been issued on `st`.
+hipError_t ring_mark(CounterRing &r, int slot, hipStream_t st) {
+    r.used[slot] = true;
+    r.last[slot] = st;
+    return hipEventRecord(r.done[slot], st);
 }
 
 constexpr int MAX_DEVICES = 64;

@@ -165,6 +165,37 @@ def test_a_seventeenth_render_in_flight_is_refused_not_corrupted():
             hip.hipStreamDestroy(st)
 
 
+def test_any_number_of_renders_may_be_queued_on_one_stream():
+    """Stream order already keeps a counter's reset behind the launch that used it last on the same stream: forty
+    frames queued on one stream without a wait in between all render (an interactive loop or a benchmark does
+    this), through both entry points."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    W, H = 480, 270
+    with Renderer(0) as r:
+        r.set_scene(scenes.by_name("random_spheres"))
+        st = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(st)) == 0
+        for noalloc in (False, True):
+            buf = _DevBuf(hip, W * H * 4)
+            for i in range(40):
+                r.render_device(RenderParams(W, H, samples_per_pixel=64, max_depth=50, seed=i), buf, None, None, st.value,
+                                noalloc=noalloc)
+            assert hip.hipDeviceSynchronize() == 0
+            got = buf.to_numpy(np.uint8, (H, W, 4))
+            buf.free()
+            want = _render(r, RenderParams(W, H, samples_per_pixel=64, max_depth=50, seed=39), False)[0]
+            assert np.array_equal(got, want), f"noalloc={noalloc}"
+        hip.hipStreamDestroy(st)
+
+
 def test_noalloc_rejects_what_it_cannot_count():
     from raytracer_amd import RtError
 
