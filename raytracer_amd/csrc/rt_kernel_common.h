@@ -38,6 +38,9 @@ constexpr bool is_mfma(int src) { return src == SRC_MFMA || src == SRC_MFMA_STRE
 // they come (16 waves: one workgroup per CU at four waves per SIMD), and its queue only ever holds
 // the remainder of one batch plus one turn of the recording loop.
 constexpr size_t MF_LDS_BYTES = 159 * 1024; // dynamic LDS a workgroup of the matrix-core variants may use: a CU has 160 KiB, and the workgroup-wide vote of the streamed variant keeps a little static LDS
+#ifndef RT_MF_THREADS
+#define RT_MF_THREADS 1024
+#endif
 #ifndef RT_MF_STREAM_THREADS
 #define RT_MF_STREAM_THREADS 1024
 #endif
@@ -47,7 +50,7 @@ constexpr size_t MF_LDS_BYTES = 159 * 1024; // dynamic LDS a workgroup of the ma
 #define RT_MF_FULL_THREADS 768
 #endif
 constexpr int wg_threads_of(int src, bool full = false) {
-    return src == SRC_MFMA ? (full ? RT_MF_FULL_THREADS : 1024)
+    return src == SRC_MFMA ? (full ? RT_MF_FULL_THREADS : RT_MF_THREADS)
            : src == SRC_MFMA_STREAMED ? (full ? RT_MF_FULL_THREADS : RT_MF_STREAM_THREADS) : WG_THREADS;
 }
 // (the streamed variant's waves scan in step, a barrier per table tile, so a wave that stops to decide a batch holds

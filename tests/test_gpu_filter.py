@@ -442,7 +442,7 @@ def test_primary_ray_lists_change_no_byte(case, monkeypatch):
         scene.camera = scenes.make_camera((0.0, 1.0, 0.0), (1.0, -0.1, 0.3))
     elif case == "behind":         # most of the scene behind the camera
         scene.camera = scenes.make_camera((3.0, 0.6, 1.0), (1.0, 0.05, 0.2))
-    elif case in ("thin", "thin8"):  # 1x1- and 4x2-pixel tiles of a 4K frame: pyramids 10^-4 rad across, where the cosine
+    elif case in ("thin", "thin8"):  # 1x1- and 8x1-pixel tiles of a 4K frame: pyramids 10^-4 rad across, where the cosine
         W, H, spp = 3840, 2160, 6    # of the opening angle rounds to 1 and neighbouring corner directions are parallel in float
         monkeypatch.setenv("RT_AMD_TILE", "0" if case == "thin" else "3")
     elif case == "depth1":         # primary rays only: with lists hardly a scan (tiles whose list is too long)
