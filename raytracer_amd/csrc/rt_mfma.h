@@ -16,7 +16,10 @@
 // 9 x 3 slots for the geometric terms, 2 for q (its partner is the constant 1), 2 for the per-ray term
 // (partner 1) = 31 of the 32 k slots.  Both sides are scaled by 2^10 so that the low halves of all
 // but negligible numbers are normal f16 values.  What is dropped and rounded is bounded by about
-// 2^-19 of sum |a_i b_i| <= 5 (frame units); the accumulation in the matrix pipe adds less than that.
+// 2^-19 of sum |a_i b_i| <= 5 (frame units); the accumulation in the matrix pipe adds at most 32 * 2^-24 of that
+// sum (K = 32 float additions).  tests/test_filter_bound.py rebuilds both operand sides bit for bit on the CPU and
+// checks |representation error| + accumulation bound < m for every pair of three scenes, origins up to sixty cloud
+// radii out: the worst pair uses 0.28 of m, the sum of magnitudes reaches 4.6.
 // The per-ray term carries the margin m = MF_MARGIN + 2^-20 max|O'_i| (the second part covers the
 // rounding of O' itself for origins far from the cloud), so the sign of the result errs only towards
 // "candidate": like the packed filter, this one may pass a sphere the ray misses and never drops one it
