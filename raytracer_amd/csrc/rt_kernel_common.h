@@ -127,7 +127,7 @@ struct KParams {
     int n_quads;     // sphere quads to scan (padding included)
     int n_spheres;   // spheres of the scene
     int n_lights;    // lights shaded at every hit (0 unless RT_FLAG_DIRECT_LIGHT)
-    int prim_min;    // primary-ray lists: a scan runs when at least this many lanes need one (0: no lists, every ray takes the scan)
+    int prim_min;    // primary-ray lists: 0 = none, every ray takes the scan; general kernels: a scan runs when at least this many lanes need one
     MfmaFrame mf;    // frame of the matrix-core filter table (SRC_MFMA)
     float inv_w, inv_h;
     float cam[12];   // center, upper_left, right, down
