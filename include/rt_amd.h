@@ -351,7 +351,7 @@ typedef struct rt_filter_info {
     int32_t n_big;      /* spheres decided outside the filter ... */
     int32_t big[8];     /* ... and their indices; their columns never pass */
     int32_t n_table_rows; /* rows of the table the kernel multiplies (the other spheres along a space-filling
-                           * curve, padded to blocks of 32 and, when streamed through LDS, to tiles of 16 blocks) */
+                           * curve, padded to blocks of 32 and, when streamed through LDS, to tiles of 20 blocks) */
 } rt_filter_info;
 int rt_filter_describe(rt_ctx *ctx, rt_filter_info *out);
 /* Filter values of n rays (origin, direction: 3 floats each, direction of any length) against every sphere,

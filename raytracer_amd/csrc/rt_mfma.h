@@ -58,7 +58,8 @@ constexpr float MF_NEVER = 60000.0f;     // magnitude that outweighs every other
 struct MfmaFrame {
     float cx, cy, cz; // c0: centre of the cloud
     float scale;      // MF_SCALE / Rs
-    int n_blocks;     // table blocks of 32 spheres (row = sphere index; rows past the list never pass)
+    int n_blocks;     // table blocks of 32 rows, padded to whole tiles when the table may be streamed (rows past the list never pass)
+    int n_used;       // blocks that hold a sphere: what a scan of the resident table walks
     int n_big;
     int big[MF_MAX_BIG]; // indices of the spheres decided directly
 };
@@ -265,19 +266,25 @@ __device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, 
     cq.slot[lane] = NO_HIT_KEY;
     int count = 0; // queue fill, wave-uniform
     sec.mark(8); // tuning build: 8 = matrix products and sign masks, 9 = recording, 10 = decisions, 11 = the rest
-    mfma_scan_blocks(tab + lane, 0, fr.n_blocks, op, cq, count, lane, o, dh, tmin, self_id, rows, sec);
+    mfma_scan_blocks(tab + lane, 0, fr.n_used, op, cq, count, lane, o, dh, tmin, self_id, rows, sec);
     mfma_scan_finish(fr, cq, count, lane, o, dh, live, tmin, self_id, sph, rows, best_t, best_id, sec);
 }
 
 // The same with a table too large for LDS: it passes through two LDS buffers of MF_TILE_BLOCKS blocks,
 // the whole workgroup scanning in step (one barrier per tile; every wave of the workgroup must call this,
-// with or without rays).  A thread fetches its share of the next tile into registers before the wave
-// works on the current one and stores it afterwards, so the fetch costs no waiting.
+// with or without rays).  Before a wave works on the current tile its threads send their share of the next
+// one from memory straight into the other buffer (global_load_lds_dwordx4: no registers, no LDS stores), so
+// the fetch costs no waiting.
+// (20 blocks: the longest tiles two buffers of which fit beside sixteen waves' state; a scan of 10 001 spheres then
+// crosses 16 barriers instead of 20, 1.6 % of its frame)
 #ifndef RT_MF_TILE_BLOCKS
-#define RT_MF_TILE_BLOCKS 16
+#define RT_MF_TILE_BLOCKS 20
 #endif
 constexpr int MF_TILE_BLOCKS = RT_MF_TILE_BLOCKS;
 constexpr int MF_TILE_WORDS = (MF_TILE_BLOCKS + 1) * MF_BLOCK_WORDS; // with the block the read-ahead touches
+#ifndef RT_MF_GLDS
+#define RT_MF_GLDS 1 // the next tile goes from memory straight into LDS (global_load_lds_dwordx4); 0: through registers
+#endif
 template <int WG_THREADS_T, int QUEUE_CAP, class F>
 __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *__restrict__ gtab, const F &fr, V3 o, V3 dh,
                                                    bool live, float tmin, int self_id, int lane, const CandQ &cq,
@@ -291,6 +298,37 @@ __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *_
     int count = 0;
     const int n_tiles = fr.n_blocks / MF_TILE_BLOCKS; // the table is padded to whole tiles
     const int tid = threadIdx.x;
+#if RT_MF_GLDS
+    // Tile t of the table into buffer `buf`, without passing through registers: every lane names its own 16 bytes of
+    // the table, and a wave's 1 KiB lands at the wave's (uniform) LDS address + 16 x lane, which is where the
+    // lane-linear copy of the tile wants them.  (tid + k * WG_THREADS_T < TILE is the same for all lanes of a wave.)
+    auto fetch = [&](int t, int buf) {
+        const uint4v *g = gtab + (size_t)t * TILE;
+        uint4v *dst = bufs + buf * MF_TILE_WORDS;
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; ++k)
+            if (EVEN || tid + k * WG_THREADS_T < TILE)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(g + tid + k * WG_THREADS_T),
+                    (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)(dst + tid + k * WG_THREADS_T), 16, 0, 0);
+    };
+    // the previous scan's readers of buffer 0 are done: every wave has passed the last barrier of that scan
+    fetch(0, 0);
+    sec.mark(12); // tuning build: 12 = first tile and its barrier, 13 = the barriers between tiles
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this thread's part of the tile has landed
+    __syncthreads();
+    sec.mark(8);
+    for (int t = 0; t < n_tiles; ++t) {
+        // buffer (t + 1) & 1 held tile t - 1, which every wave has finished with (the barrier that ended it)
+        if (t + 1 < n_tiles) fetch(t + 1, (t + 1) & 1);
+        mfma_scan_blocks<QUEUE_CAP - 64>(bufs + (t & 1) * MF_TILE_WORDS + lane, t * MF_TILE_BLOCKS, MF_TILE_BLOCKS, op, cq, count,
+                                         lane, o, dh, tmin, self_id, rows, sec);
+        sec.mark(13);
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+        __syncthreads(); // the next tile is complete, and nobody still reads the buffer after it
+        sec.mark(8);
+    }
+#else
     uint4v next[PER_THREAD];
     // the previous scan's readers of buffer 0 are done: every wave has passed the last barrier of that scan
 #pragma unroll
@@ -318,6 +356,7 @@ __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *_
         __syncthreads(); // the next tile is complete, and nobody still reads the buffer after it
         sec.mark(8);
     }
+#endif
     mfma_scan_finish(fr, cq, count, lane, o, dh, live, tmin, self_id, sph, rows, best_t, best_id, sec);
 }
 

@@ -190,7 +190,7 @@ def test_strained_frames_drop_no_hit(name):
         info = r.filter_describe()
         assert info["in_use"] and info["n_rows"] >= len(scene.spheres) - len(info["big"])
         if name.startswith("edge"):
-            assert not info["big"] and info["n_rows"] == (1440 if name == "edge_resident" else 1536)  # whole tiles of 16 blocks
+            assert not info["big"] and info["n_rows"] == (1440 if name == "edge_resident" else 1920)  # whole tiles of 20 blocks
         org, d = _rays(scene, 4096, rng, spread=info["radius"])
         # a few origins very far out, aimed back at the cloud
         far = rng.random(len(org)) < 0.05
