@@ -161,13 +161,13 @@ __device__ __forceinline__ f2 pair_filter(const RayK &r, float4 A, float4 B) {
 
 // Tuning build only (-DRT_SECTIONS): wave cycles per part of the render loop, from s_memtime stamps.
 #ifdef RT_SECTIONS
-__device__ unsigned long long g_sections[16];
+__device__ unsigned long long g_sections[24];
 struct SecClock {
-    unsigned long long t[16];
+    unsigned long long t[24];
     unsigned long long last;
     int cur;
     __device__ __forceinline__ void start() {
-        for (int k = 0; k < 16; ++k) t[k] = 0;
+        for (int k = 0; k < 24; ++k) t[k] = 0;
         last = __builtin_amdgcn_s_memtime();
         cur = 7;
     }

@@ -46,6 +46,8 @@ struct FullScene {
     cptr<float> verts;        // polygon vertices, xyz
     cptr<int32_t> others;     // indices of the non-sphere primitives, ascending
     cptr<int32_t> halo;       // indices taking part in the halo pass (selected ones and planes), ascending
+    const float4 *halo_bound; // per entry of `halo`: a sphere (centre, radius) around the primitive grown by EXPAND_COEF;
+                              // radius -1 marks a plane, which has none
     cptr<int32_t> sph_gid;    // packed sphere index -> primitive index
     int n_others, n_halo;
 };
@@ -197,7 +199,8 @@ __device__ __forceinline__ void other_hit(const FullScene &fs, int idx, V3 o, V3
 // precision the two passes compute that t by different formulas and the tie can break either way, so
 // here the flag is that of the final record alone and the caller takes this record only when it lies on
 // a grown shell.
-__device__ __forceinline__ Closest halo_pass(const FullScene &fs, V3 o, V3 d, float tmin) {
+// `in_view`: bit k clear leaves out entry k of the list (k < 64); the caller knows that the ray misses it, plain and grown.
+__device__ __forceinline__ Closest halo_pass(const FullScene &fs, V3 o, V3 d, float tmin, unsigned long long in_view = ~0ull) {
     Closest e;
     e.t = __builtin_inff();
     e.prim = -1;
@@ -205,6 +208,7 @@ __device__ __forceinline__ Closest halo_pass(const FullScene &fs, V3 o, V3 d, fl
     e.box_face = 0;
     e.expanded = false;
     for (int k = 0; k < fs.n_halo; ++k) {
+        if (k < 64 && !((in_view >> k) & 1ull)) continue;
         const int idx = fs.halo[k];
         const DPrim pr = load_prim(fs.prims, idx);
         float t = 0.f;

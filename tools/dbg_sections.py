@@ -11,7 +11,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "random_spheres"
 W, H, spp, depth = (int(x) for x in (sys.argv[2:6] if len(sys.argv) > 5 else (1200, 675, 500, 50)))
 flags = 2 if len(sys.argv) > 6 else 0
 lib = load_library()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 r = Renderer(0); r.set_scene(scenes.by_name(name))
 r.render_host(RenderParams(W, H, spp, depth, flags=flags))
 lib.rt_debug_sections(out, 1)
@@ -23,7 +23,8 @@ v[14] = v[15] = 0
 tot = sum(v)
 names = ["ray set-up + scan", "shade", "accumulate", "store tiles", "hand-out", "rng + raygen/scatter", "-", "outside loop",
          "scan: matrix products + sign masks", "scan: recording candidates", "scan: deciding candidates",
-         "scan: big spheres + result", "streamed: first tile + barrier", "streamed: tile barriers", "-", "-"]
+         "scan: big spheres + result", "streamed: first tile + barrier", "streamed: tile barriers", "-", "-",
+         "general: other primitive kinds", "general: halo pass", "general: shadow query's result", "-", "-", "-", "-", "-"]
 print(f"{name} {W}x{H} {spp} spp: kernel {r.last_kernel_ms():.2f} ms, rays {rays}, scans {r.last_scans()}, in-kernel shader clock {clock_ghz:.3f} GHz")
 for n, x in zip(names, v):
-    if x: print(f"  {n:24s} {100.0 * x / tot:6.2f} % of wave cycles")
+    if x: print(f"  {n:34s} {100.0 * x / tot:6.2f} % of wave cycles")
