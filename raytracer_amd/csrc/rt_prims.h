@@ -22,7 +22,8 @@ struct DPrim {
     float p[8];
     uint32_t selected;
     int32_t sph_local; // spheres: index in the packed scan arrays, else -1
-    uint32_t _pad[2];
+    uint32_t first_edge; // polygons: first of its n_vertices records in FullScene::edges
+    uint32_t _pad;
 };
 
 static_assert(sizeof(DPrim) == 64, "load_prim reads a primitive as four 16-byte words");
@@ -35,7 +36,7 @@ __device__ __forceinline__ DPrim load_prim(cptr<DPrim> list, int idx) {
     r.type = a.x; r.mat = a.y; r.first_vertex = a.z; r.n_vertices = a.w;
     r.p[0] = __uint_as_float(b.x); r.p[1] = __uint_as_float(b.y); r.p[2] = __uint_as_float(b.z); r.p[3] = __uint_as_float(b.w);
     r.p[4] = __uint_as_float(c.x); r.p[5] = __uint_as_float(c.y); r.p[6] = __uint_as_float(c.z); r.p[7] = __uint_as_float(c.w);
-    r.selected = d.x; r.sph_local = (int32_t)d.y; r._pad[0] = d.z; r._pad[1] = d.w;
+    r.selected = d.x; r.sph_local = (int32_t)d.y; r.first_edge = d.z; r._pad = d.w;
     return r;
 }
 
@@ -44,6 +45,10 @@ struct FullScene {
     // and get scalar loads
     cptr<DPrim> prims;        // every primitive, in insertion order
     cptr<float> verts;        // polygon vertices, xyz
+    cptr<float4> edges;       // per polygon vertex i, as the polygon test reads it: (x_i, y_i, x_j - x_i, y_j - y_i + 1e-20) in the
+                              // polygon's 2D projection, j the vertex before i; n_edges records for the polygons as they are
+                              // (DPrim::first_edge), then n_edges for the polygons grown by EXPAND_COEF; built on the host
+    int n_edges;
     cptr<int32_t> others;     // indices of the non-sphere primitives, ascending
     cptr<int32_t> halo;       // indices taking part in the halo pass (selected ones and planes), ascending
     const float4 *halo_bound; // per entry of `halo`: a sphere (centre, radius) around the primitive grown by EXPAND_COEF;
@@ -57,7 +62,6 @@ struct Closest {
     float t;
     int prim;       // primitive index, -1 = none
     float scale;    // 1, or EXPAND_COEF when the hit is on a halo shell
-    int box_face;   // cubes: 0..5 = -x,+x,-y,+y,-z,+z of the slab that produced t
     bool expanded;  // HitRecord::hitExpanded
 };
 
@@ -96,17 +100,18 @@ __device__ __forceinline__ bool plane_t(V3 o, V3 d, float tmin, float tmax, cons
     return true;
 }
 
-// CubeObject::hitBox, inc/RTObjects.h:593-620.  Also reports which slab face produced t: in double
-// precision the reference finds that face by testing the hit point against the six faces within
-// 1e-6 (:626-631); in single precision the point itself is not that accurate, the slab is.
-__device__ __forceinline__ bool box_t(V3 o, V3 d, float tmin_i, float tmax_i, V3 center, V3 half, float &t, int &face) {
+// CubeObject::hitBox, inc/RTObjects.h:593-620: the slab test, entry and exit times (tn, tf) of the ray's line through the
+// box and the faces (0..5 = -x,+x,-y,+y,-z,+z) that produce them; false when the line misses the box.  `scale` grows the
+// half size (1, or EXPAND_COEF for the halo, :560-568); the slab bounds centre -+ half * scale are one fused
+// multiply-add each, spelled out so that every copy of this arithmetic rounds alike.
+__device__ __forceinline__ bool box_slabs(V3 o, V3 d, V3 center, V3 half, float scale, float &tn, float &tf, int &fn, int &ff) {
     float tmin = -__builtin_inff(), tmax = __builtin_inff();
     int fmin = 0, fmax = 0;
     const float orig[3] = {o.x, o.y, o.z}, dir[3] = {d.x, d.y, d.z};
     const float cen[3] = {center.x, center.y, center.z}, hs[3] = {half.x, half.y, half.z};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        float lo = cen[i] - hs[i], hi = cen[i] + hs[i];
+        const float lo = fmaf(-hs[i], scale, cen[i]), hi = fmaf(hs[i], scale, cen[i]);
         if (fabsf(dir[i]) < 1e-12f) {
             if (orig[i] < lo || orig[i] > hi) return false;
         } else {
@@ -122,23 +127,73 @@ __device__ __forceinline__ bool box_t(V3 o, V3 d, float tmin_i, float tmax_i, V3
             if (tmax < tmin) return false;
         }
     }
-    if (tmin > tmin_i && tmin < tmax_i) { t = tmin; face = fmin; return true; }
-    if (tmax > tmin_i && tmax < tmax_i) { t = tmax; face = fmax; return true; }
+    tn = tmin; tf = tmax; fn = fmin; ff = fmax;
+    return true;
+}
+
+// The hit of the slab test inside (tmin_i, tmax_i): the entry time if it lies there, else the exit time.
+// The closest-hit loops only need t, and for all but a wave that holds a ray parallel to an axis plane the slab
+// test is minima and maxima: the entry time is the largest of the three nearer slab times, the exit time the
+// smallest of the farther ones, and "exit before entry" at any axis shows in the final pair as well (entry only
+// grows, exit only shrinks).  Same operations on the same operands as box_slabs(), so the same t; the face is
+// looked up by box_face() for the one box that wins.
+__device__ __forceinline__ bool box_t(V3 o, V3 d, float tmin_i, float tmax_i, V3 center, V3 half, float scale, float &t) {
+    float tn, tf;
+    if (__ballot(fabsf(d.x) < 1e-12f || fabsf(d.y) < 1e-12f || fabsf(d.z) < 1e-12f)) {
+        int fn, ff;
+        if (!box_slabs(o, d, center, half, scale, tn, tf, fn, ff)) return false;
+    } else {
+        const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+        const float x0 = (fmaf(-half.x, scale, center.x) - o.x) * ix, x1 = (fmaf(half.x, scale, center.x) - o.x) * ix;
+        const float y0 = (fmaf(-half.y, scale, center.y) - o.y) * iy, y1 = (fmaf(half.y, scale, center.y) - o.y) * iy;
+        const float z0 = (fmaf(-half.z, scale, center.z) - o.z) * iz, z1 = (fmaf(half.z, scale, center.z) - o.z) * iz;
+        tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        if (tf < tn) return false;
+    }
+    if (tn > tmin_i && tn < tmax_i) { t = tn; return true; }
+    if (tf > tmin_i && tf < tmax_i) { t = tf; return true; }
     return false;
 }
 
+// The face a box was hit on at time t (a time box_t() returned for this ray and box): in double precision the
+// reference finds it by testing the hit point against the six faces within 1e-6 (inc/RTObjects.h:626-631); in
+// single precision the point itself is not that accurate, the slab that produced t is.
+__device__ __forceinline__ int box_face(V3 o, V3 d, V3 center, V3 half, float scale, float t) {
+    float tn = 0.f, tf = 0.f;
+    int fn = 0, ff = 0;
+    (void)box_slabs(o, d, center, half, scale, tn, tf, fn, ff);
+    return t == tn ? fn : ff;
+}
+
 // PolygonObject::projectTo2D, inc/RTObjects.h:444-453
-__device__ __forceinline__ void project2d(V3 n, V3 p, float &u, float &v) {
+__host__ __device__ __forceinline__ void project2d(V3 n, V3 p, float &u, float &v) {
     float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
     if (ax > ay && ax > az) { u = p.y; v = p.z; }
     else if (ay > az) { u = p.x; v = p.z; }
     else { u = p.x; v = p.y; }
 }
 
-// PolygonObject::hitDetail + pointInPolygon2D, inc/RTObjects.h:455-497; `scale` pushes the vertices
-// away from the centroid for the halo (:375-381).
-__device__ __forceinline__ bool polygon_t(V3 o, V3 d, float tmin, float tmax, const DPrim &pr, cptr<float> verts,
-                                          float scale, float &t) {
+// One record of FullScene::edges: vertex i of a polygon pushed away from the centroid by `scale` (1, or EXPAND_COEF for
+// the halo, inc/RTObjects.h:375-381) and projected (projectTo2D), with its difference to the vertex before it.  The
+// operations and their order are those of pointInPolygon2D's crossing test (inc/RTObjects.h:455-497).
+__host__ __device__ __forceinline__ void polygon_edge(V3 n, V3 cen, V3 vi, V3 vj, float scale, float out[4]) {
+    vi = madd(cen, vi - cen, scale);
+    vj = madd(cen, vj - cen, scale);
+    float xi, yi, xj, yj;
+    project2d(n, vi, xi, yi);
+    project2d(n, vj, xj, yj);
+    out[0] = xi;
+    out[1] = yi;
+    out[2] = xj - xi;
+    const float dy = yj - yi;
+    out[3] = dy + 1e-20f;
+}
+
+// PolygonObject::hitDetail + pointInPolygon2D, inc/RTObjects.h:455-497, over the edge records of the polygon as it is
+// or grown (`grown`).
+__device__ __forceinline__ bool polygon_t(V3 o, V3 d, float tmin, float tmax, const DPrim &pr, const FullScene &fs,
+                                          bool grown, float &t) {
     const int nv = (int)pr.n_vertices;
     if (nv < 3) return false;
     V3 n = mk(pr.p[0], pr.p[1], pr.p[2]), cen = mk(pr.p[3], pr.p[4], pr.p[5]);
@@ -150,18 +205,14 @@ __device__ __forceinline__ bool polygon_t(V3 o, V3 d, float tmin, float tmax, co
     float px, py;
     project2d(n, p, px, py);
     bool inside = false;
-    cptr<float> vv = verts + 3 * pr.first_vertex;
-    V3 vj = mk(vv[3 * (nv - 1)], vv[3 * (nv - 1) + 1], vv[3 * (nv - 1) + 2]);
-    vj = madd(cen, vj - cen, scale);
+    cptr<float4> ee = fs.edges + ((grown ? fs.n_edges : 0) + (int)pr.first_edge);
+    bool above_j = load_const4(ee, nv - 1).y > py; // the vertex before the first is the last
     for (int i = 0; i < nv; ++i) {
-        V3 vi = mk(vv[3 * i], vv[3 * i + 1], vv[3 * i + 2]);
-        vi = madd(cen, vi - cen, scale);
-        float xi, yi, xj, yj;
-        project2d(n, vi, xi, yi);
-        project2d(n, vj, xj, yj);
-        bool cross = ((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) * __builtin_amdgcn_rcpf(yj - yi + 1e-20f) + xi);
+        const float4 e = load_const4(ee, i);
+        const bool above_i = e.y > py;
+        const bool cross = (above_i != above_j) && (px < fmaf(e.z * (py - e.y), __builtin_amdgcn_rcpf(e.w), e.x));
         inside = inside != cross;
-        vj = vi;
+        above_j = above_i;
     }
     if (!inside) return false;
     t = time;
@@ -172,19 +223,16 @@ __device__ __forceinline__ bool polygon_t(V3 o, V3 d, float tmin, float tmax, co
 __device__ __forceinline__ void other_hit(const FullScene &fs, int idx, V3 o, V3 d, float tmin, Closest &c) {
     const DPrim pr = load_prim(fs.prims, idx);
     float t = 0.f;
-    int face = 0;
     bool ok;
     // the interval's upper end is inclusive here and the tie is settled by beats()
     const float tmax = __builtin_inff();
     if (pr.type == PRIM_PLANE) ok = plane_t(o, d, tmin, tmax, pr, t);
-    else if (pr.type == PRIM_CUBE)
-        ok = box_t(o, d, tmin, tmax, mk(pr.p[0], pr.p[1], pr.p[2]), mk(pr.p[3], pr.p[4], pr.p[5]), t, face);
-    else ok = polygon_t(o, d, tmin, tmax, pr, fs.verts, 1.0f, t);
+    else if (pr.type == PRIM_CUBE) ok = box_t(o, d, tmin, tmax, mk(pr.p[0], pr.p[1], pr.p[2]), mk(pr.p[3], pr.p[4], pr.p[5]), 1.0f, t);
+    else ok = polygon_t(o, d, tmin, tmax, pr, fs, false, t);
     if (ok && beats(t, idx, c)) {
         c.t = t;
         c.prim = idx;
         c.scale = 1.0f;
-        c.box_face = face;
         c.expanded = false;
     }
 }
@@ -205,14 +253,12 @@ __device__ __forceinline__ Closest halo_pass(const FullScene &fs, V3 o, V3 d, fl
     e.t = __builtin_inff();
     e.prim = -1;
     e.scale = 1.0f;
-    e.box_face = 0;
     e.expanded = false;
     for (int k = 0; k < fs.n_halo; ++k) {
         if (k < 64 && !((in_view >> k) & 1ull)) continue;
         const int idx = fs.halo[k];
         const DPrim pr = load_prim(fs.prims, idx);
         float t = 0.f;
-        int face = 0;
         bool ok = false, grown = false;
         if (pr.type == PRIM_PLANE) {
             ok = plane_t(o, d, tmin, e.t, pr, t);
@@ -222,17 +268,16 @@ __device__ __forceinline__ Closest halo_pass(const FullScene &fs, V3 o, V3 d, fl
             if (!ok) { ok = sphere_t(o, d, tmin, e.t, c, pr.p[3] * EXPAND_COEF, t); grown = ok; }
         } else if (pr.type == PRIM_CUBE) {
             V3 c = mk(pr.p[0], pr.p[1], pr.p[2]), hs = mk(pr.p[3], pr.p[4], pr.p[5]);
-            ok = box_t(o, d, tmin, e.t, c, hs, t, face);
-            if (!ok) { ok = box_t(o, d, tmin, e.t, c, hs * EXPAND_COEF, t, face); grown = ok; }
+            ok = box_t(o, d, tmin, e.t, c, hs, 1.0f, t);
+            if (!ok) { ok = box_t(o, d, tmin, e.t, c, hs, EXPAND_COEF, t); grown = ok; }
         } else {
-            ok = polygon_t(o, d, tmin, e.t, pr, fs.verts, 1.0f, t);
-            if (!ok) { ok = polygon_t(o, d, tmin, e.t, pr, fs.verts, EXPAND_COEF, t); grown = ok; }
+            ok = polygon_t(o, d, tmin, e.t, pr, fs, false, t);
+            if (!ok) { ok = polygon_t(o, d, tmin, e.t, pr, fs, true, t); grown = ok; }
         }
         if (ok) {
             e.t = t;
             e.prim = idx;
             e.scale = grown ? EXPAND_COEF : 1.0f;
-            e.box_face = face;
             e.expanded = grown;
         }
     }
@@ -255,8 +300,9 @@ __device__ __forceinline__ Hit finish_any(const FullScene &fs, V3 o, V3 d, const
         outward = dot(n, d) < 0.0f ? n * -1.0f : n; // turned along the ray: a plane is never front-facing
         object = c.prim;
     } else if (pr.type == PRIM_CUBE) {
-        float s = (c.box_face & 1) ? 1.0f : -1.0f;
-        int axis = c.box_face >> 1;
+        const int face = box_face(o, d, mk(pr.p[0], pr.p[1], pr.p[2]), mk(pr.p[3], pr.p[4], pr.p[5]), c.scale, c.t);
+        float s = (face & 1) ? 1.0f : -1.0f;
+        int axis = face >> 1;
         outward = mk(axis == 0 ? s : 0.f, axis == 1 ? s : 0.f, axis == 2 ? s : 0.f);
         object = OBJ_NULL;
     } else {
