@@ -244,6 +244,12 @@ int rt_last_kernel_variant(const rt_ctx *ctx);
  * Replaces nothing in the reference; for measurement. */
 uint64_t rt_last_scans(const rt_ctx *ctx);
 
+/* Table blocks (32 rows against the 64 rays of a wave, four matrix instructions) the scans of the last
+ * rt_render_host() call walked: scans x blocks of the table, fewer when the kernel walks a long table only where a
+ * wave's rays can meet a block's bounding sphere (variant 5; the blocks of the table of bounds count too).
+ * Replaces nothing in the reference; for measurement. */
+uint64_t rt_last_blocks(const rt_ctx *ctx);
+
 /* First-hit flags */
 enum {
     RT_FH_REFINE = 1u << 0,  /* re-test numerically ambiguous rays in fp64 so that the

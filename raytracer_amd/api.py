@@ -84,7 +84,7 @@ class RenderParams:
 EXPORTS = [
     "rt_version", "rt_rng4", "rt_rng4_device_host", "rt_output_rows", "rt_create", "rt_destroy", "rt_last_error",
     "rt_upload_scene", "rt_upload_scene_ex", "rt_upload_lights", "rt_set_camera", "rt_render", "rt_render_noalloc",
-    "rt_render_host", "rt_last_kernel_ms", "rt_last_kernel_variant", "rt_last_scans", "rt_device_allocations", "rt_filter_describe", "rt_filter_values_host",
+    "rt_render_host", "rt_last_kernel_ms", "rt_last_kernel_variant", "rt_last_scans", "rt_last_blocks", "rt_device_allocations", "rt_filter_describe", "rt_filter_values_host",
     "rt_group_create", "rt_group_destroy", "rt_group_last_error", "rt_group_size", "rt_group_transport",
     "rt_group_device_allocations", "rt_group_upload_scene_ex", "rt_group_upload_lights", "rt_group_set_camera",
     "rt_group_render", "rt_group_render_host",
@@ -157,6 +157,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     _proto(lib, "rt_last_kernel_variant", "restype", C.c_int)
     _proto(lib, "rt_last_scans", "argtypes", [vp])
     _proto(lib, "rt_last_scans", "restype", C.c_uint64)
+    _proto(lib, "rt_last_blocks", "argtypes", [vp])
+    _proto(lib, "rt_last_blocks", "restype", C.c_uint64)
     _proto(lib, "rt_device_allocations", "argtypes", [vp])
     _proto(lib, "rt_device_allocations", "restype", C.c_uint64)
     _proto(lib, "rt_group_create", "argtypes", [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)])
@@ -355,12 +357,17 @@ class Renderer:
 
     def last_kernel_variant(self) -> int:
         """Sphere source of the last render's kernel (0 LDS copy, 1 LDS tiles, 2 scalar loads, 3 matrix-core filter
-        resident, 4 streamed), + 8 for the general kernel; -1 before the first render."""
+        resident, 4 streamed, 5 read from memory where a block's bound is met), + 8 for the general kernel; -1 before
+        the first render."""
         return int(self.lib.rt_last_kernel_variant(self.h))
 
     def last_scans(self) -> int:
         """Scans (closest-sphere searches for the 64 rays of a wave) the last render_host's kernel ran."""
         return int(self.lib.rt_last_scans(self.h))
+
+    def last_blocks(self) -> int:
+        """Table blocks (32 rows x the 64 rays of a wave) the scans of the last render_host's kernel walked."""
+        return int(self.lib.rt_last_blocks(self.h))
 
     def device_allocations(self) -> int:
         return int(self.lib.rt_device_allocations(self.h))

@@ -31,8 +31,8 @@ constexpr size_t CQ_BYTES = WAVES_PER_WG * (CAND_CAP * sizeof(unsigned) + 64 * s
 constexpr size_t WAVE_STATE_BYTES = ACC_BYTES + CQ_BYTES;
 
 // Where the scan loop takes the sphere words from.
-enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2, SRC_MFMA = 3, SRC_MFMA_STREAMED = 4 };
-constexpr bool is_mfma(int src) { return src == SRC_MFMA || src == SRC_MFMA_STREAMED; }
+enum { SRC_LDS_RESIDENT = 0, SRC_LDS_STREAMED = 1, SRC_SCALAR = 2, SRC_MFMA = 3, SRC_MFMA_STREAMED = 4, SRC_MFMA_CULLED = 5 };
+constexpr bool is_mfma(int src) { return src == SRC_MFMA || src == SRC_MFMA_STREAMED || src == SRC_MFMA_CULLED; }
 
 // The matrix-core variant shares one filter table per workgroup, so its workgroups are as large as
 // they come (16 waves: one workgroup per CU at four waves per SIMD), and its queue only ever holds
@@ -50,7 +50,7 @@ constexpr size_t MF_LDS_BYTES = 159 * 1024; // dynamic LDS a workgroup of the ma
 #define RT_MF_FULL_THREADS 768
 #endif
 constexpr int wg_threads_of(int src, bool full = false) {
-    return src == SRC_MFMA ? (full ? RT_MF_FULL_THREADS : RT_MF_THREADS)
+    return src == SRC_MFMA || src == SRC_MFMA_CULLED ? (full ? RT_MF_FULL_THREADS : RT_MF_THREADS)
            : src == SRC_MFMA_STREAMED ? (full ? RT_MF_FULL_THREADS : RT_MF_STREAM_THREADS) : WG_THREADS;
 }
 // (the streamed variant's waves scan in step, a barrier per table tile, so a wave that stops to decide a batch holds
@@ -144,7 +144,8 @@ struct DeviceScene {
     const DLight *lights;
     const uint4v *mf_table; // matrix-core filter table, MF_BLOCK_WORDS 16-byte words per 32 spheres
     const float4 *mf_rows;  // the sphere (cx, cy, cz, r) behind every table row ...
-    const int *mf_row_idx;  // ... and its index in `sph` (rows are in the order of a space-filling curve)
+    const int *mf_row_idx;  // ... and its index in `sph` (rows are in the leaf order of a k-d partition)
+    const uint4v *mf_coarse; // the table of block bounds in front of a table too long for LDS (MfmaFrame::n_coarse + 1 blocks)
     FullScene full; // general primitive list (used by the FULL kernel variants only)
 };
 
@@ -155,7 +156,8 @@ struct KArgs {
     uchar4 *rgba;
     float4 *accum;                // may be null
     unsigned long long *rays_out; // may be null
-    unsigned long long *scans_out; // may be null: receives the number of scans the waves ran (64 lanes each)
+    unsigned long long *scans_out; // may be null: receives the number of scans the waves ran (64 lanes each) and, in the next
+                                   // word, the table blocks (32 rows x 64 lanes) they walked when blocks are culled by their bounds
     unsigned *queue;              // work counter, zero at launch
 };
 
