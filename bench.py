@@ -186,11 +186,14 @@ class Job:
         return dt, kern, gath, int(self.rays.item())
 
     def count_scans(self):
-        """Scans (64 lanes each) of one frame at seed 0, from one more frame rendered through the host entry
-        point outside any timed region."""
+        """(scans, table blocks walked) of one frame at seed 0, from one more frame rendered through the host entry
+        point outside any timed region.  A scan finds the closest sphere for the 64 rays of a wave; a block is 32
+        table rows against those 64 rays (four matrix instructions).  A kernel that walks the whole table walks
+        rows / 32 blocks per scan; the one that reads a long table only where a block's bounding sphere is met by
+        some ray of the wave walks fewer (the blocks of its table of bounds count too)."""
         self.p.seed = 0
         self.r.render_host(self.p)
-        return self.r.last_scans()
+        return self.r.last_scans(), self.r.last_blocks()
 
     def roofline(self, kern_ms, rays_per_launch, args):
         n_s = self.scene.n_spheres
@@ -205,8 +208,8 @@ class Job:
             # lanes of its wave).  What BOUNDS the kernel is named by `bound`: the busier of the SIMD's vector
             # issue port and its matrix pipe in the committed counter profile of this workload.
             rows = info.get("table_rows") or info["n_rows"]
-            scans = self.count_scans()
-            mfma = scans * 64 * FLOP_PER_ROW_MFMA * rows / (kern_ms * 1e-3) / 1e12
+            scans, blocks = self.count_scans()
+            mfma = blocks * 32 * 64 * FLOP_PER_ROW_MFMA / (kern_ms * 1e-3) / 1e12
             issue_busy, mfma_busy, busy_src = committed_busy(self.name, args, self.world)
             bound = "mfma" if issue_busy is None or mfma_busy >= issue_busy else "valu_issue"
             return {
@@ -229,10 +232,14 @@ class Job:
                 "traffic_source": traffic_src,
                 "kernel": "render_kernel",
                 "kernel_ms": round(kern_ms, 3),
-                "flop_model": f"matrix: scans*64 lanes*{FLOP_PER_ROW_MFMA}*{rows} table rows; algorithmic: "
-                              f"rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}); rays/launch={rays_per_launch:.0f}, scans/launch={scans}",
+                "flop_model": f"matrix: blocks walked*32 rows*64 lanes*{FLOP_PER_ROW_MFMA}; algorithmic: "
+                              f"rays*({FLOP_PER_TEST}*{n_s}+{FLOP_PER_RAY}); rays/launch={rays_per_launch:.0f}, scans/launch={scans}, "
+                              f"blocks/launch={blocks}, table rows={rows}",
                 "scanned_ray_share": round(scans * 64 / max(rays_per_launch, 1), 4),
-                "note": "frac prices the matrix products issued (scans x 64 lanes x rows) against the matrix peak; with "
+                # 1 when every scan walks the whole table; below 1 when a long table is read only where a block's
+                # bounding sphere is met by some ray of the wave
+                "table_share_walked": round(blocks * 32 / max(scans * rows, 1), 4),
+                "note": "frac prices the matrix products issued (blocks walked x 32 rows x 64 lanes) against the matrix peak; with "
                         "bound = valu_issue the headroom is instruction count, not frac; brute_force is the same frame "
                         "with every ray scanned against every sphere",
             }
@@ -261,12 +268,12 @@ class Job:
             return None
         rows = info.get("table_rows") or info["n_rows"]
         sdt, skern, _, srays = self.run(steps, 1, sync)
-        scans = self.count_scans()
+        scans, blocks = self.count_scans()
         n_s = self.scene.n_spheres
-        products = scans * 64 * FLOP_PER_ROW_MFMA * rows
+        products = blocks * 32 * 64 * FLOP_PER_ROW_MFMA
         alg = srays / steps * (FLOP_PER_TEST * n_s + FLOP_PER_RAY)
         return {
-            "switch": "RT_AMD_PRIM_MIN=0",
+            "switch": "RT_AMD_PRIM_MIN=0 RT_AMD_BLOCK_CULL=0",
             "value": round(self.W * self.H * self.cfg["spp"] * steps / sdt / 1e6, 3),
             "unit": "Msamples/s",
             "ms_per_step": round(sdt / steps * 1e3, 3),
@@ -405,10 +412,11 @@ def main():
             # dominant kernel: render_kernel on this rank; algorithmic FLOPs of one launch / its duration
             "roofline": job.roofline(kern_ms, my_rays / args.steps, args),
         }
-        if world == 1 and args.workload == "c4" and not args.spp and not args.no_secondary:
-            bf = Job(args.workload, args, rank, world, local_rank, dev, args.accum, ctx_env={"RT_AMD_PRIM_MIN": "0"})
+        if world == 1 and args.workload in ("c4", "c5") and not args.spp and not args.no_secondary:
+            bf = Job(args.workload, args, rank, world, local_rank, dev, args.accum, ctx_env={"RT_AMD_PRIM_MIN": "0", "RT_AMD_BLOCK_CULL": "0"})
             out["roofline"]["brute_force"] = bf.brute_force(max(min(args.steps, 3), 1), sync)
             del bf
+        if world == 1 and args.workload == "c4" and not args.spp and not args.no_secondary:
             sec = Job("c3", args, rank, world, local_rank, dev, args.accum)
             n = max(args.steps, 5)
             sdt, skern, _, srays = sec.run(n, 1, sync)

@@ -63,9 +63,12 @@ constexpr int cand_cap_of(int src) { return src == SRC_MFMA_STREAMED ? RT_MF_STR
 constexpr size_t acc_bytes_of(int src, bool full = false) {
     return (size_t)(wg_threads_of(src, full) / 64) * WAVE_LDS_WORDS * sizeof(unsigned long long);
 }
+// the variant that culls table blocks by their bounds notes per wave which blocks it wants: one word per 32 blocks
+constexpr int MF_COARSE_MAX = 48;
 constexpr size_t wave_state_bytes_of(int src, bool full = false) {
     return acc_bytes_of(src, full) +
-           (size_t)(wg_threads_of(src, full) / 64) * (cand_cap_of(src) * sizeof(unsigned) + 64 * sizeof(unsigned long long));
+           (size_t)(wg_threads_of(src, full) / 64) * (cand_cap_of(src) * sizeof(unsigned) + 64 * sizeof(unsigned long long) +
+                                                      (src == SRC_MFMA_CULLED ? MF_COARSE_MAX * sizeof(uint32_t) : 0));
 }
 static_assert(wave_state_bytes_of(SRC_SCALAR) == WAVE_STATE_BYTES, "the plain variants keep their layout");
 

@@ -275,102 +275,115 @@ __device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, 
     mfma_scan_finish(fr, cq, count, lane, o, dh, live, tmin, self_id, sph, rows, best_t, best_id, sec);
 }
 
-// Filter of the table blocks blk_base + b for every set bit b of `mask` (wave-uniform, not 0), the blocks' words
-// read from memory (`gtab_lane`: the table at this lane's 16 bytes): what mfma_scan_blocks does for a run of
-// blocks in LDS.  The words of the next wanted block are requested before the current block's results are
-// examined.  `visited` counts the blocks walked.
-template <int FLUSH_AT = 64>
-__device__ __forceinline__ void mfma_scan_masked(const uint4v *__restrict__ gtab_lane, int blk_base, uint32_t mask,
-                                                 const RayOperand &op, const CandQ &cq, int &count, int lane, V3 o, V3 dh,
-                                                 float tmin, int self_id, const float4 *__restrict__ sph, unsigned &visited,
-                                                 SecClock &sec) {
-    const unsigned lane_part = (unsigned)(lane & 31) | ((unsigned)(lane >> 5) << 10);
-    int blk = blk_base + (int)__builtin_ctz(mask);
-    mask &= mask - 1;
-    half8 a0 = __builtin_bit_cast(half8, gtab_lane[(size_t)(2 * blk) * 64]);
-    half8 a1 = __builtin_bit_cast(half8, gtab_lane[(size_t)(2 * blk + 1) * 64]);
-    float16v acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
-#pragma unroll 1
-    for (;;) {
-        ++visited;
-        const float16v acc1 = mfma_tile(a0, a1, op.b[1][0], op.b[1][1]);
-        const bool more = mask != 0;
-        const int nxt = more ? blk_base + (int)__builtin_ctz(mask) : blk;
-        if (more) {
-            a0 = __builtin_bit_cast(half8, gtab_lane[(size_t)(2 * nxt) * 64]);
-            a1 = __builtin_bit_cast(half8, gtab_lane[(size_t)(2 * nxt + 1) * 64]);
-        }
-        const bool some = __ballot((int)(or16(acc0) | or16(acc1)) < 0) != 0;
-        uint32_t m = 0;
-        if (some) m = gather32(acc0, acc1);
-        if (more) acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
-        if (some) {
-            RT_STAT(2);
-            sec.mark(9);
-            const unsigned block_part = lane_part | ((unsigned)blk << 11);
-            for (unsigned long long any = __ballot(m != 0); any != 0; any = __ballot(m != 0)) {
-                RT_STAT(3);
-                if (m != 0) {
-                    RT_STAT_LANES(5);
-                    const unsigned bit = (unsigned)__builtin_ctz(m);
-                    m &= m - 1;
-                    cq.ent[count + lane_rank(any)] = block_part + (bit << 5);
-                }
-                count += (int)__popcll(any);
-                if (count >= FLUSH_AT) {
-                    sec.mark(10);
-                    do resolve_batch(cq, count, 64, lane, o, dh, tmin, self_id, sph);
-                    while (count >= 64);
-                    sec.mark(9);
-                }
-            }
-            sec.mark(8);
-        }
-        if (!more) break;
-        mask &= mask - 1;
-        blk = nxt;
-    }
-}
-
-// Which rows of a coarse block pass for ANY ray of the wave: bit b = row b of the block (register v of lanes 0-31 is
-// row v, of lanes 32-63 row 16 + v, see mfma_tile).  Wave-uniform.
+// Which rows of a table block pass for ANY ray of the wave: bit b = row b of the block (register v of lanes 0-31 is
+// row v, of lanes 32-63 row 16 + v, see mfma_tile).  Wave-uniform; the lane masks of the comparisons are taken apart
+// on the scalar unit.
 __device__ __forceinline__ uint32_t rows_any_lane(const float16v &acc0, const float16v &acc1) {
     uint32_t rows = 0;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-        const unsigned long long b = __ballot((int)(__float_as_uint(acc0[v]) | __float_as_uint(acc1[v])) < 0);
-        rows |= ((uint32_t)b != 0u ? 1u << v : 0u) | ((uint32_t)(b >> 32) != 0u ? 1u << (16 + v) : 0u);
+        unsigned long long b = __ballot((int)(__float_as_uint(acc0[v]) | __float_as_uint(acc1[v])) < 0);
+        asm("" : "+s"(b)); // a scalar register pair from here on: its halves are tested with scalar compares
+        const uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+        rows |= (lo != 0u ? 1u << v : 0u) | (hi != 0u ? 1u << (16 + v) : 0u);
     }
     return rows;
 }
 
 // The same for a table too long for LDS, with the table of block bounds (`ctab`, resident in LDS, fr.n_coarse blocks
-// and one more readable one) in front of it: the filter runs over the bounds, 32 blocks per coarse block, and then
-// over those blocks of the table whose bound passes for some ray of the wave, read from memory (`gtab`).  A block
-// whose bound no ray's line meets holds no sphere any of the rays can hit, so the winner is the one scan_mfma finds.
-// Whole wave, no workgroup step: the waves of a workgroup scan independently.
-template <class F>
-__device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4v *__restrict__ gtab, const F &fr, V3 o, V3 dh,
-                                                 bool live, float tmin, int self_id, int lane, const CandQ &cq,
+// and one more readable one) in front of it.  First the filter runs over the bounds, 32 blocks per coarse block,
+// and notes per coarse block which of its 32 blocks are wanted: those whose bound passes for some ray of the wave
+// (`wanted`: fr.n_coarse words of this wave in LDS).  Then it runs over the wanted blocks of the table in one
+// loop, their words read from memory (`gtab`) one block ahead of the products, candidates through the queue as in
+// mfma_scan_blocks.  A block whose bound no ray's line meets holds no sphere any of the rays can hit, so the winner
+// is the one scan_mfma finds.  Whole wave, no workgroup step: the waves of a workgroup scan independently.
+// `visited` counts the blocks walked, those of the table of bounds included.
+template <int FLUSH_AT = 64, class F>
+__device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4v *__restrict__ gtab, uint32_t *wanted, const F &fr,
+                                                 V3 o, V3 dh, bool live, float tmin, int self_id, int lane, const CandQ &cq,
                                                  const float4 *__restrict__ sph, const float4 *__restrict__ rows,
                                                  float &best_t, int &best_id, unsigned &visited, SecClock &sec) {
     const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
     cq.slot[lane] = NO_HIT_KEY;
     int count = 0;
     sec.mark(8);
-    const uint4v *clane = ctab + lane;
-    const uint4v *glane = gtab + lane;
-    half8 c0 = __builtin_bit_cast(half8, clane[0]), c1 = __builtin_bit_cast(half8, clane[64]);
     const int n_coarse = fr.n_coarse;
+    {
+        const uint4v *clane = ctab + lane;
+        half8 c0 = __builtin_bit_cast(half8, clane[0]), c1 = __builtin_bit_cast(half8, clane[64]);
 #pragma unroll 1
-    for (int cb = 0; cb < n_coarse; ++cb) {
-        const float16v acc0 = mfma_tile(c0, c1, op.b[0][0], op.b[0][1]);
-        const float16v acc1 = mfma_tile(c0, c1, op.b[1][0], op.b[1][1]);
-        c0 = __builtin_bit_cast(half8, clane[(2 * cb + 2) * 64]);
-        c1 = __builtin_bit_cast(half8, clane[(2 * cb + 3) * 64]);
-        const uint32_t wanted = rows_any_lane(acc0, acc1);
-        ++visited;
-        if (wanted != 0) mfma_scan_masked(glane, cb * MF_BLOCK, wanted, op, cq, count, lane, o, dh, tmin, self_id, rows, visited, sec);
+        for (int cb = 0; cb < n_coarse; ++cb) {
+            const float16v acc0 = mfma_tile(c0, c1, op.b[0][0], op.b[0][1]);
+            const float16v acc1 = mfma_tile(c0, c1, op.b[1][0], op.b[1][1]);
+            c0 = __builtin_bit_cast(half8, clane[(2 * cb + 2) * 64]);
+            c1 = __builtin_bit_cast(half8, clane[(2 * cb + 3) * 64]);
+            const uint32_t w = rows_any_lane(acc0, acc1);
+            if (lane == 0) wanted[cb] = w;
+        }
+        visited += (unsigned)n_coarse;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // the wanted blocks in ascending order, -1 after the last (wave-uniform)
+    int next_word = 0, word_base = 0;
+    uint32_t word = 0;
+    auto next_block = [&]() -> int {
+        while (word == 0) {
+            if (next_word >= n_coarse) return -1;
+            word = (uint32_t)__builtin_amdgcn_readfirstlane((int)wanted[next_word]);
+            word_base = next_word * MF_BLOCK;
+            ++next_word;
+        }
+        const int b = word_base + (int)__builtin_ctz(word);
+        word &= word - 1;
+        return b;
+    };
+    const unsigned lane_part = (unsigned)(lane & 31) | ((unsigned)(lane >> 5) << 10);
+    const uint4v *glane = gtab + lane;
+    int blk = next_block();
+    if (blk >= 0) {
+        half8 a0 = __builtin_bit_cast(half8, glane[(size_t)(2 * blk) * 64]);
+        half8 a1 = __builtin_bit_cast(half8, glane[(size_t)(2 * blk + 1) * 64]);
+        int nxt = next_block();
+        float16v acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
+#pragma unroll 1
+        for (;;) {
+            ++visited;
+            const float16v acc1 = mfma_tile(a0, a1, op.b[1][0], op.b[1][1]);
+            const bool more = nxt >= 0;
+            if (more) {
+                a0 = __builtin_bit_cast(half8, glane[(size_t)(2 * nxt) * 64]);
+                a1 = __builtin_bit_cast(half8, glane[(size_t)(2 * nxt + 1) * 64]);
+            }
+            const bool some = __ballot((int)(or16(acc0) | or16(acc1)) < 0) != 0;
+            uint32_t m = 0;
+            if (some) m = gather32(acc0, acc1);
+            if (more) acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
+            if (some) {
+                RT_STAT(2);
+                sec.mark(9);
+                const unsigned block_part = lane_part | ((unsigned)blk << 11);
+                for (unsigned long long any = __ballot(m != 0); any != 0; any = __ballot(m != 0)) {
+                    RT_STAT(3);
+                    if (m != 0) {
+                        RT_STAT_LANES(5);
+                        const unsigned bit = (unsigned)__builtin_ctz(m);
+                        m &= m - 1;
+                        cq.ent[count + lane_rank(any)] = block_part + (bit << 5);
+                    }
+                    count += (int)__popcll(any);
+                    if (count >= FLUSH_AT) {
+                        sec.mark(10);
+                        do resolve_batch(cq, count, 64, lane, o, dh, tmin, self_id, rows);
+                        while (count >= 64);
+                        sec.mark(9);
+                    }
+                }
+                sec.mark(8);
+            }
+            if (!more) break;
+            blk = nxt;
+            nxt = next_block();
+        }
     }
     mfma_scan_finish(fr, cq, count, lane, o, dh, live, tmin, self_id, sph, rows, best_t, best_id, sec);
 }

@@ -315,13 +315,16 @@ def _light_above(box):
     return lights
 
 
-@pytest.mark.parametrize("n,variant,others", [(1473, 8 + 3, False), (2600, 8 + 4, False), (2600, 8 + 4, True)])
-def test_general_kernel_streams_a_table_too_long_for_lds(n, variant, others, oracle64, monkeypatch):
+@pytest.mark.parametrize("n,variant,others,cull", [(1473, 8 + 3, False, True), (2600, 8 + 5, False, True), (2600, 8 + 4, False, False),
+                                                   (2600, 8 + 5, True, True), (2600, 8 + 4, True, False)])
+def test_general_kernel_streams_a_table_too_long_for_lds(n, variant, others, cull, oracle64, monkeypatch):
     """A lit scene (Camera::computeDirectLighting, reference src/Camera.cpp:161-178) of more spheres than a table
     resident in LDS holds: the general kernel streams the table through LDS in tiles like the sphere-only kernel
     does (its workgroup is smaller, so a table the sphere-only kernel already streams may still be resident for it:
-    the first case; the last adds a floor plane, a box and a selected sphere with its halo).  Which kernel ran is asked of the library; bytes, sums and ray counts equal the packed
-    filter's, and the frame is the oracle's."""
+    the first case; the last two add a floor plane, a box and a selected sphere with its halo).  By default such a table
+    is read from memory block by block where a wave's rays can meet a block's bounding sphere (variant 5); with
+    RT_AMD_BLOCK_CULL=0 the whole table passes through LDS in tiles (variant 4).  Which kernel ran is asked of the
+    library; bytes, sums and ray counts equal the packed filter's, and the frame is the oracle's."""
     from raytracer_amd.api import FLAG_DIRECT_LIGHT
 
     box = (30.0, 30.0, 4.0)
@@ -334,14 +337,16 @@ def test_general_kernel_streams_a_table_too_long_for_lds(n, variant, others, ora
     scene.lights = _light_above(box)
     W, H, spp, depth = 96, 64, 12, 12
     p = RenderParams(W, H, spp, depth, seed=4, flags=FLAG_DIRECT_LIGHT)
+    if not cull:
+        monkeypatch.setenv("RT_AMD_BLOCK_CULL", "0")
     with Renderer(0) as r:
         r.set_scene(scene)
         assert r.last_kernel_variant() == -1
         a = r.render_host(p, want_accum=True)
-        assert r.last_kernel_variant() == variant  # general kernel, table resident (3) / streamed (4)
+        assert r.last_kernel_variant() == variant  # general kernel, table resident (3) / streamed (4) / read where bounds are met (5)
         ms_mfma = r.last_kernel_ms()
         r.render_host(RenderParams(W, H, spp, depth, seed=4))  # no lights asked for: the sphere-only kernel, if spheres are all there is
-        assert r.last_kernel_variant() == (variant if others else 4)
+        assert r.last_kernel_variant() == (variant if others else (5 if cull else 4))
     monkeypatch.setenv("RT_AMD_SPHERE_SOURCE", "scalar")
     with Renderer(0) as r:
         r.set_scene(scene)
