@@ -57,6 +57,7 @@ constexpr float MF_MARGIN = 3.0517578125e-5f;     // 2^-15, in frame units (radi
 constexpr float MF_MARGIN_FAR = 9.5367431640625e-7f; // 2^-20 per frame unit of max|O'_i|
 constexpr float MF_CULL = 1.002f;        // a line farther than this from the centre meets no table sphere
 constexpr float MF_NEVER = 60000.0f;     // magnitude that outweighs every other term
+constexpr float MF_STRETCH_MAX = 4.0f;   // the most a thin axis of the cloud is stretched in the frame of the block bounds
 
 // What the kernel needs to know about the table (part of the launch parameters).
 struct MfmaFrame {
@@ -65,6 +66,7 @@ struct MfmaFrame {
     int n_blocks;     // table blocks of 32 rows, padded to whole tiles when the table may be streamed (rows past the list never pass)
     int n_used;       // blocks that hold a sphere: what a scan of the resident table walks
     int n_coarse;     // blocks of the table of block bounds in front of a table too long for LDS (0: none)
+    float csx, csy, csz; // the bounds' own frame: MF_SCALE / its radius per axis, a flat cloud's thin axes stretched (scan_mfma_culled)
     int n_big;
     int big[MF_MAX_BIG]; // indices of the spheres decided directly
 };
@@ -93,10 +95,11 @@ struct RayOperand {
 //   w = 15       : (t_hi, t_lo)                [1, 1]
 // Lane l of a 32x32x16 operand holds k = 8 (l >> 5) + j of its row / column (j = 0..7), so a lane's own
 // sixteen words are exchanged between the wave's halves (v_permlane32_swap) into the four operands.
-__device__ __forceinline__ RayOperand mfma_ray_operand(V3 o, V3 dh, bool live, float cx, float cy, float cz, float scale) {
+// (`scale`: MF_SCALE over the frame's radius, per axis; `dh`: the ray's unit direction in that frame)
+__device__ __forceinline__ RayOperand mfma_ray_operand(V3 o, V3 dh, bool live, float cx, float cy, float cz, V3 scale) {
     // O' scaled by MF_SCALE; p in two steps: the first lands on the line near the centre (any multiple
     // of dh does), the second removes what is left along dh, so p's error does not grow with |O'|^2
-    const V3 oc = mk((o.x - cx) * scale, (o.y - cy) * scale, (o.z - cz) * scale);
+    const V3 oc = mk((o.x - cx) * scale.x, (o.y - cy) * scale.y, (o.z - cz) * scale.z);
     const V3 o2 = madd(oc, dh, -dot(oc, dh));
     const V3 p = madd(o2, dh, -dot(o2, dh));
     const float pp = dot(p, p) * (1.0f / MF_SCALE); // MF_SCALE * |p|^2
@@ -267,7 +270,7 @@ template <class F> // MfmaFrame, in whatever address space the launch parameters
 __device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, V3 dh, bool live, float tmin,
                                           int self_id, int lane, const CandQ &cq, const float4 *__restrict__ sph,
                                           const float4 *__restrict__ rows, float &best_t, int &best_id, SecClock &sec) {
-    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
+    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, mk(fr.scale, fr.scale, fr.scale));
     cq.slot[lane] = NO_HIT_KEY;
     int count = 0; // queue fill, wave-uniform
     sec.mark(8); // tuning build: 8 = matrix products and sign masks, 9 = recording, 10 = decisions, 11 = the rest
@@ -303,12 +306,17 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
                                                  V3 o, V3 dh, bool live, float tmin, int self_id, int lane, const CandQ &cq,
                                                  const float4 *__restrict__ sph, const float4 *__restrict__ rows,
                                                  float &best_t, int &best_id, unsigned &visited, SecClock &sec) {
-    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
     cq.slot[lane] = NO_HIT_KEY;
     int count = 0;
     sec.mark(8);
     const int n_coarse = fr.n_coarse;
     {
+        // The bounds live in a frame of their own: the axes along which the cloud is thin are stretched (a flat field of
+        // spheres would otherwise get bounds that reach as far above it as along it), and a line stays a line.  The ray's
+        // direction in that frame is its direction times the axis scales, made a unit vector again.
+        const V3 cs = mk(fr.csx, fr.csy, fr.csz);
+        const V3 ds = mk(dh.x * cs.x, dh.y * cs.y, dh.z * cs.z);
+        const RayOperand op = mfma_ray_operand(o, ds * __frsqrt_rn(dot(ds, ds)), live, fr.cx, fr.cy, fr.cz, cs);
         const uint4v *clane = ctab + lane;
         half8 c0 = __builtin_bit_cast(half8, clane[0]), c1 = __builtin_bit_cast(half8, clane[64]);
 #pragma unroll 1
@@ -323,6 +331,7 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
         visited += (unsigned)n_coarse;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, mk(fr.scale, fr.scale, fr.scale));
     // the wanted blocks in ascending order, -1 after the last (wave-uniform)
     int next_word = 0, word_base = 0;
     uint32_t word = 0;
@@ -411,7 +420,7 @@ __device__ __forceinline__ void scan_mfma_streamed(uint4v *bufs, const uint4v *_
     constexpr int TILE = MF_TILE_BLOCKS * MF_BLOCK_WORDS;                  // 16-byte words of a tile
     constexpr int PER_THREAD = (TILE + WG_THREADS_T - 1) / WG_THREADS_T;   // ... per thread
     constexpr bool EVEN = PER_THREAD * WG_THREADS_T == TILE;               // else the last turn is for some threads only
-    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, fr.scale);
+    const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, mk(fr.scale, fr.scale, fr.scale));
     cq.slot[lane] = NO_HIT_KEY;
     int count = 0;
     const int n_tiles = fr.n_blocks / MF_TILE_BLOCKS; // the table is padded to whole tiles
