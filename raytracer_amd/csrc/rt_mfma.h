@@ -51,12 +51,15 @@ typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
 
 constexpr int MF_BLOCK = 32;             // spheres per table block (rows of one MFMA tile)
 constexpr int MF_BLOCK_WORDS = 2 * 64;   // 16-byte words per block: two k-steps x 64 lanes
+constexpr int MF_COARSE_WORDS = 3 * 64;  // ... per block of the table of block bounds: a third k-step holds the rows of the test for what lies behind a ray
 constexpr int MF_MAX_BIG = 8;            // spheres decided outside the table
 constexpr float MF_SCALE = 1024.0f;      // both operand sides are scaled by this
 constexpr float MF_MARGIN = 3.0517578125e-5f;     // 2^-15, in frame units (radius of the cloud = 1)
 constexpr float MF_MARGIN_FAR = 9.5367431640625e-7f; // 2^-20 per frame unit of max|O'_i|
 constexpr float MF_CULL = 1.002f;        // a line farther than this from the centre meets no table sphere
 constexpr float MF_NEVER = 60000.0f;     // magnitude that outweighs every other term
+constexpr float MF_AHEAD_MARGIN = 0.001953125f; // 2^-9 of the bounds' frame: a bound this little behind a ray's origin still counts as ahead
+constexpr float MF_AHEAD_CLAMP = 30.0f;  // origins farther than this before or past the cloud's centre (frame units) are treated as this far
 constexpr float MF_STRETCH_MAX = 4.0f;   // the most a thin axis of the cloud is stretched in the frame of the block bounds
 
 // What the kernel needs to know about the table (part of the launch parameters).
@@ -152,6 +155,10 @@ __device__ __forceinline__ RayOperand mfma_ray_operand(V3 o, V3 dh, bool live, f
 __device__ __forceinline__ float16v mfma_tile(half8 a0, half8 a1, half8 b0, half8 b1) {
     const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, zero, 0, 0, 0), 0, 0, 0);
+}
+// ... added to `c`
+__device__ __forceinline__ float16v mfma_tile_onto(half8 a0, half8 a1, half8 b0, half8 b1, const float16v &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0), 0, 0, 0);
 }
 
 // Sign bits of result tiles.  On this chip every vector instruction holds the
@@ -278,25 +285,73 @@ __device__ __forceinline__ void scan_mfma(const uint4v *tab, const F &fr, V3 o, 
     mfma_scan_finish(fr, cq, count, lane, o, dh, live, tmin, self_id, sph, rows, best_t, best_id, sec);
 }
 
-// Which rows of a table block pass for ANY ray of the wave: bit b = row b of the block (register v of lanes 0-31 is
-// row v, of lanes 32-63 row 16 + v, see mfma_tile).  Wave-uniform; the lane masks of the comparisons are taken apart
-// on the scalar unit.
-__device__ __forceinline__ uint32_t rows_any_lane(const float16v &acc0, const float16v &acc1) {
+// The ray side of the test for what lies behind a ray (scan_mfma_culled): one 32x32x8 product.  With U, P a bound's
+// centre and radius and o, d the ray's origin and unit direction, all in the bounds' frame, some point of the bound
+// lies ahead of the origin iff U.d + P - o.d > 0.  Eight k slots (sphere side in brackets; every product carries
+// 2^20 = MF_SCALE^2 like the filter's values: 1024 x 1024, 32 x 32768, 32 x 32768):
+//   dx [Ux]   dy [Uy]   dz [Uz]   1 [P]   t_hi [1]   t_lo [1]   0   0
+// with t = margin - o.d, clamped to +-MF_AHEAD_CLAMP (an origin farther before the cloud has all of it ahead, one
+// farther past it all of it behind, clamped or not).  Single half-floats: U, P rounded to nearest (2^-12 each) and d
+// towards zero (2^-11) put the sum off by less than 2^-11 * 1.5 |U| |d| + 2^-12 P <= 0.001 frame units, half of
+// MF_AHEAD_MARGIN.  The sphere side is negated: the result is negative for a bound that lies, at least in part, ahead,
+// and 2^20 times how far it lies behind otherwise.  That number, or zero, is what the filter's products for the bound
+// are added to: a bound the line meets (a negative filter value, at most about 2^20 P^2 in size) stays wanted unless it
+// lies behind the origin by more than the filter value says the line is inside it -- a few thousandths of the frame.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+struct AheadOperand {
+    half4 b[2]; // [ray block: lanes 0-31 / 32-63]
+};
+__device__ __forceinline__ AheadOperand mfma_ahead_operand(V3 o, V3 dh, bool live, float cx, float cy, float cz, V3 scale) {
+    const float inv = 1.0f / MF_SCALE;
+    const V3 ou = mk((o.x - cx) * scale.x * inv, (o.y - cy) * scale.y * inv, (o.z - cz) * scale.z * inv); // frame units
+    float t = fminf(fmaxf(MF_AHEAD_MARGIN - dot(ou, dh), -MF_AHEAD_CLAMP), MF_AHEAD_CLAMP) * 32.0f;
+    V3 ds = dh * MF_SCALE;
+    float one = 32.0f;
+    if (!(live && t == t)) { // no ray (or one that is not a number): nothing lies ahead of it
+        ds = mk(0, 0, 0);
+        one = 0.0f;
+        t = -1.0f;
+    }
+    const float th = half_lo(pack_rtz(t, 0.0f));
+    uint32_t w[4] = {pack_rtz(ds.x, ds.y), pack_rtz(ds.z, one), pack_rtz(th, t - th), 0u};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(w[i], w[2 + i], false, false);
+        w[i] = r0[0];
+        w[2 + i] = r0[1];
+    }
+    AheadOperand op;
+    op.b[0] = __builtin_bit_cast(half4, (uint2v){w[0], w[1]});
+    op.b[1] = __builtin_bit_cast(half4, (uint2v){w[2], w[3]});
+    return op;
+}
+
+// Which rows of a block of bounds are wanted by ANY ray of one half of the wave's rays: a negative value.  Bit b = row b
+// of the block (register v of lanes 0-31 is row v, of lanes 32-63 row 16 + v, see mfma_tile).  Wave-uniform; the lane
+// masks of the comparisons are taken apart on the scalar unit.
+__device__ __forceinline__ uint32_t rows_wanted(const float16v &m) {
     uint32_t rows = 0;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-        unsigned long long b = __ballot((int)(__float_as_uint(acc0[v]) | __float_as_uint(acc1[v])) < 0);
+        unsigned long long b = __ballot((int)__float_as_uint(m[v]) < 0);
         asm("" : "+s"(b)); // a scalar register pair from here on: its halves are tested with scalar compares
         const uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
         rows |= (lo != 0u ? 1u << v : 0u) | (hi != 0u ? 1u << (16 + v) : 0u);
     }
     return rows;
 }
+// How far a bound lies behind a ray's origin, or zero: what the filter's products for the bound are added to.
+__device__ __forceinline__ float16v behind_or_zero(float16v a) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) a[v] = fmaxf(a[v], 0.0f);
+    return a;
+}
 
 // The same for a table too long for LDS, with the table of block bounds (`ctab`, resident in LDS, fr.n_coarse blocks
-// and one more readable one) in front of it.  First the filter runs over the bounds, 32 blocks per coarse block,
-// and notes per coarse block which of its 32 blocks are wanted: those whose bound passes for some ray of the wave
-// (`wanted`: fr.n_coarse words of this wave in LDS).  Then it runs over the wanted blocks of the table in one
+// of MF_COARSE_WORDS and one more readable one) in front of it.  First the filter runs over the bounds, 32 blocks per
+// coarse block, and notes per coarse block which of its 32 blocks are wanted: those whose bound passes for some ray of
+// the wave and does not lie behind that ray's origin (`wanted`: fr.n_coarse words of this wave in LDS).  Then it runs over the wanted blocks of the table in one
 // loop, their words read from memory (`gtab`) one block ahead of the products, candidates through the queue as in
 // mfma_scan_blocks.  A block whose bound no ray's line meets holds no sphere any of the rays can hit, so the winner
 // is the one scan_mfma finds.  Whole wave, no workgroup step: the waves of a workgroup scan independently.
@@ -316,21 +371,28 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
         // direction in that frame is its direction times the axis scales, made a unit vector again.
         const V3 cs = mk(fr.csx, fr.csy, fr.csz);
         const V3 ds = mk(dh.x * cs.x, dh.y * cs.y, dh.z * cs.z);
-        const RayOperand op = mfma_ray_operand(o, ds * __frsqrt_rn(dot(ds, ds)), live, fr.cx, fr.cy, fr.cz, cs);
+        const V3 dc = ds * __frsqrt_rn(dot(ds, ds));
+        const RayOperand op = mfma_ray_operand(o, dc, live, fr.cx, fr.cy, fr.cz, cs);
+        const AheadOperand ah = mfma_ahead_operand(o, dc, live, fr.cx, fr.cy, fr.cz, cs);
         const uint4v *clane = ctab + lane;
-        half8 c0 = __builtin_bit_cast(half8, clane[0]), c1 = __builtin_bit_cast(half8, clane[64]);
+        const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
         for (int cb = 0; cb < n_coarse; ++cb) {
-            const float16v acc0 = mfma_tile(c0, c1, op.b[0][0], op.b[0][1]);
-            const float16v acc1 = mfma_tile(c0, c1, op.b[1][0], op.b[1][1]);
-            c0 = __builtin_bit_cast(half8, clane[(2 * cb + 2) * 64]);
-            c1 = __builtin_bit_cast(half8, clane[(2 * cb + 3) * 64]);
-            const uint32_t w = rows_any_lane(acc0, acc1);
+            // (no read-ahead here, and one ray half at a time: this loop has no registers for a second set of table
+            // words or a second result tile beside the two operands and the path's state)
+            const half8 c0 = __builtin_bit_cast(half8, clane[(3 * cb) * 64]), c1 = __builtin_bit_cast(half8, clane[(3 * cb + 1) * 64]);
+            const half4 c2 = *reinterpret_cast<const half4 *>(clane + (3 * cb + 2) * 64); // (the first 8 bytes of the lane's word)
+            uint32_t w = rows_wanted(mfma_tile_onto(c0, c1, op.b[0][0], op.b[0][1], behind_or_zero(__builtin_amdgcn_mfma_f32_32x32x8f16(c2, ah.b[0], zero, 0, 0, 0))));
+            __builtin_amdgcn_sched_barrier(0);
+            w |= rows_wanted(mfma_tile_onto(c0, c1, op.b[1][0], op.b[1][1], behind_or_zero(__builtin_amdgcn_mfma_f32_32x32x8f16(c2, ah.b[1], zero, 0, 0, 0))));
+            __builtin_amdgcn_sched_barrier(0);
             if (lane == 0) wanted[cb] = w;
         }
         visited += (unsigned)n_coarse;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    // (the table's own ray operand is formed only now: sixteen registers the loop above has no room for)
+    asm volatile("" : "+v"(o.x), "+v"(dh.x));
     const RayOperand op = mfma_ray_operand(o, dh, live, fr.cx, fr.cy, fr.cz, mk(fr.scale, fr.scale, fr.scale));
     // the wanted blocks in ascending order, -1 after the last (wave-uniform)
     int next_word = 0, word_base = 0;
@@ -346,12 +408,18 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
         word &= word - 1;
         return b;
     };
-    const unsigned lane_part = (unsigned)(lane & 31) | ((unsigned)(lane >> 5) << 10);
-    const uint4v *glane = gtab + lane;
+    // the table as a buffer: a block's words are at the block's (scalar) byte offset plus this lane's 16 bytes, so a
+    // load costs no address arithmetic in vector registers
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4v *>(gtab), 0, (fr.n_blocks + 1) * MF_BLOCK_WORDS * 16, 0x00020000);
+    const int lane_bytes = lane * 16;
+    auto block_words = [&](int b, half8 &w0, half8 &w1) {
+        w0 = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(tab, lane_bytes, b * (MF_BLOCK_WORDS * 16), 0));
+        w1 = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(tab, lane_bytes, b * (MF_BLOCK_WORDS * 16) + 1024, 0));
+    };
     int blk = next_block();
     if (blk >= 0) {
-        half8 a0 = __builtin_bit_cast(half8, glane[(size_t)(2 * blk) * 64]);
-        half8 a1 = __builtin_bit_cast(half8, glane[(size_t)(2 * blk + 1) * 64]);
+        half8 a0, a1;
+        block_words(blk, a0, a1);
         int nxt = next_block();
         float16v acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
 #pragma unroll 1
@@ -359,10 +427,7 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
             ++visited;
             const float16v acc1 = mfma_tile(a0, a1, op.b[1][0], op.b[1][1]);
             const bool more = nxt >= 0;
-            if (more) {
-                a0 = __builtin_bit_cast(half8, glane[(size_t)(2 * nxt) * 64]);
-                a1 = __builtin_bit_cast(half8, glane[(size_t)(2 * nxt + 1) * 64]);
-            }
+            if (more) block_words(nxt, a0, a1);
             const bool some = __ballot((int)(or16(acc0) | or16(acc1)) < 0) != 0;
             uint32_t m = 0;
             if (some) m = gather32(acc0, acc1);
@@ -370,7 +435,11 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
             if (some) {
                 RT_STAT(2);
                 sec.mark(9);
-                const unsigned block_part = lane_part | ((unsigned)blk << 11);
+                // (the lane's part of a queue entry is worked out here, where it is needed, not kept in a register
+                // across the scan: this kernel has none to spare)
+                unsigned ln = (unsigned)lane;
+                asm volatile("" : "+v"(ln));
+                const unsigned block_part = (ln & 31u) | ((ln >> 5) << 10) | ((unsigned)blk << 11);
                 for (unsigned long long any = __ballot(m != 0); any != 0; any = __ballot(m != 0)) {
                     RT_STAT(3);
                     if (m != 0) {
