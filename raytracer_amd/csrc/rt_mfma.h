@@ -60,7 +60,10 @@ constexpr float MF_CULL = 1.002f;        // a line farther than this from the ce
 constexpr float MF_NEVER = 60000.0f;     // magnitude that outweighs every other term
 constexpr float MF_AHEAD_MARGIN = 0.001953125f; // 2^-9 of the bounds' frame: a bound this little behind a ray's origin still counts as ahead
 constexpr float MF_AHEAD_CLAMP = 30.0f;  // origins farther than this before or past the cloud's centre (frame units) are treated as this far
-constexpr float MF_STRETCH_MAX = 4.0f;   // the most a thin axis of the cloud is stretched in the frame of the block bounds
+#ifndef RT_MF_STRETCH_MAX
+#define RT_MF_STRETCH_MAX 4.0f
+#endif
+constexpr float MF_STRETCH_MAX = RT_MF_STRETCH_MAX;   // the most a thin axis of the cloud is stretched in the frame of the block bounds
 
 // What the kernel needs to know about the table (part of the launch parameters).
 struct MfmaFrame {
@@ -344,7 +347,11 @@ __device__ __forceinline__ uint32_t rows_wanted(const float16v &m) {
 // How far a bound lies behind a ray's origin, or zero: what the filter's products for the bound are added to.
 __device__ __forceinline__ float16v behind_or_zero(float16v a) {
 #pragma unroll
+#ifdef RT_MF_PROBE_NO_AHEAD // tuning probe: nothing counts as lying behind
+    for (int v = 0; v < 16; ++v) a[v] = 0.0f;
+#else
     for (int v = 0; v < 16; ++v) a[v] = fmaxf(a[v], 0.0f);
+#endif
     return a;
 }
 
@@ -386,6 +393,9 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
             __builtin_amdgcn_sched_barrier(0);
             w |= rows_wanted(mfma_tile_onto(c0, c1, op.b[1][0], op.b[1][1], behind_or_zero(__builtin_amdgcn_mfma_f32_32x32x8f16(c2, ah.b[1], zero, 0, 0, 0))));
             __builtin_amdgcn_sched_barrier(0);
+#ifdef RT_MF_PROBE_WANT_ALL // tuning probe: every block is walked (the words past the table's end are rows that never pass)
+            w = cb * MF_BLOCK + MF_BLOCK <= fr.n_used ? ~0u : (1u << (fr.n_used - cb * MF_BLOCK)) - 1u;
+#endif
             if (lane == 0) wanted[cb] = w;
         }
         visited += (unsigned)n_coarse;
@@ -424,10 +434,22 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
         float16v acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
 #pragma unroll 1
         for (;;) {
+#ifndef RT_MF_PROBE_NO_VISITED
             ++visited;
+#endif
             const float16v acc1 = mfma_tile(a0, a1, op.b[1][0], op.b[1][1]);
             const bool more = nxt >= 0;
+#ifdef RT_MF_PROBE_NOPS
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+#ifdef RT_MF_PROBE_WAIT_ALL
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
             if (more) block_words(nxt, a0, a1);
+#ifdef RT_MF_PROBE_WAIT_AFTER
+            __builtin_amdgcn_s_waitcnt(0);
+            asm volatile("" ::: "memory");
+#endif
             const bool some = __ballot((int)(or16(acc0) | or16(acc1)) < 0) != 0;
             uint32_t m = 0;
             if (some) m = gather32(acc0, acc1);

@@ -105,3 +105,47 @@ def test_a_frame_rendered_in_strips_is_the_same_with_the_cut(monkeypatch):
             s = rank + 3 * k
             frame[8 * s:8 * s + 8] = part[8 * k:8 * k + 8]
     assert np.array_equal(frame, whole[0])
+
+
+def _field(n, lit):
+    """n - 1 spheres of radius 0.3 scattered over a square on a ground sphere, overlapping where chance has it (glass,
+    metal and diffuse in turn), seen from above one corner; with a light every hit sends a shadow query."""
+    rng = np.random.default_rng(n)
+    b = scenes._Builder()
+    mats = [b.lambertian((0.6, 0.5, 0.4)), b.metal((0.8, 0.8, 0.7), 0.1), b.dielectric((1.0, 1.0, 1.0), 1.5)]
+    b.sphere((0, 0, -1000.0), 1000.0, mats[0])
+    side = max(2.0, n ** 0.5)
+    for i in range(n - 1):
+        b.sphere(((rng.random() - 0.5) * side, (rng.random() - 0.5) * side, 0.3), 0.3, mats[i % 3])
+    if lit:
+        b.light((3.0, -2.0, 6.0), (0.03, 0.03, 0.03), (0.5, 0.5, 0.45), (0.8, 0.8, 0.8), 24.0)
+    return b.build("field", scenes.make_camera((side, -0.8 * side, 0.5 * side + 1), (-side, 0.8 * side, -0.5 * side - 0.5)))
+
+
+@pytest.mark.parametrize("n,lit", [(2000, True), (5000, True), (5000, False)])
+def test_a_large_frame_is_the_same_bytes_every_time_and_with_every_kernel(n, lit, monkeypatch):
+    """A hundred million rays through thousands of waves: the kernel that walks the wanted blocks renders the frame three
+    times to the same bytes, and they are the bytes of the kernel that streams the whole table and of the packed
+    filter's kernel.  (What a wave walks depends on which rays share it, which changes from run to run; the frame may
+    not.  The general kernel with primary-ray lists once failed exactly this, in a few tiles of some runs.)"""
+    scene = _field(n, lit)
+    p = RenderParams(960, 540, 64 if lit else 32, 50, seed=0, flags=FLAG_DIRECT_LIGHT if lit else 0)
+    want = (8 if lit else 0) + 5
+    runs = []
+    monkeypatch.setenv("RT_AMD_BLOCK_CULL", "1")
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        for _ in range(3):
+            runs.append(r.render_host(p, want_accum=True))
+        assert r.last_kernel_variant() == want
+    streamed = _render(scene, p, False, monkeypatch)
+    assert streamed[3] == want - 1
+    monkeypatch.setenv("RT_AMD_SPHERE_SOURCE", "scalar")
+    with Renderer(0) as r:
+        r.set_scene(scene)
+        packed = r.render_host(p, want_accum=True)
+        assert r.last_kernel_variant() == (8 if lit else 0) + 2
+    for k, a in enumerate(runs):
+        assert a[2] == packed[2] == streamed[2], f"run {k}: ray counts {a[2]}, streamed {streamed[2]}, packed filter {packed[2]}"
+        assert np.array_equal(a[1], packed[1]) and np.array_equal(a[0], packed[0]), f"run {k} differs from the packed filter's frame"
+    assert np.array_equal(streamed[1], packed[1]) and np.array_equal(streamed[0], packed[0])
