@@ -350,7 +350,9 @@ __device__ __forceinline__ float16v behind_or_zero(float16v a) {
 #ifdef RT_MF_PROBE_NO_AHEAD // tuning probe: nothing counts as lying behind
     for (int v = 0; v < 16; ++v) a[v] = 0.0f;
 #else
-    for (int v = 0; v < 16; ++v) a[v] = fmaxf(a[v], 0.0f);
+    // (as integers: a negative float is a negative integer, a positive one keeps its bits; one instruction, where fmaxf
+    // costs two for the sake of signalling NaNs -- a NaN only comes from a lane without a ray, which wants nothing)
+    for (int v = 0; v < 16; ++v) a[v] = __int_as_float(max(__float_as_int(a[v]), 0));
 #endif
     return a;
 }
@@ -434,22 +436,12 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
         float16v acc0 = mfma_tile(a0, a1, op.b[0][0], op.b[0][1]);
 #pragma unroll 1
         for (;;) {
-#ifndef RT_MF_PROBE_NO_VISITED
             ++visited;
-#endif
             const float16v acc1 = mfma_tile(a0, a1, op.b[1][0], op.b[1][1]);
-            const bool more = nxt >= 0;
-#ifdef RT_MF_PROBE_NOPS
-            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
-#ifdef RT_MF_PROBE_WAIT_ALL
-            __builtin_amdgcn_s_waitcnt(0);
-#endif
+            int nxt_s = nxt;
+            asm("" : "+s"(nxt_s)); // wave-uniform, and tested on the scalar unit
+            const bool more = nxt_s >= 0;
             if (more) block_words(nxt, a0, a1);
-#ifdef RT_MF_PROBE_WAIT_AFTER
-            __builtin_amdgcn_s_waitcnt(0);
-            asm volatile("" ::: "memory");
-#endif
             const bool some = __ballot((int)(or16(acc0) | or16(acc1)) < 0) != 0;
             uint32_t m = 0;
             if (some) m = gather32(acc0, acc1);
