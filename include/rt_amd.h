@@ -356,8 +356,8 @@ typedef struct rt_filter_info {
     int32_t n_rows;     /* columns of rt_filter_values_host: one per sphere index, padded to a multiple of 32 */
     int32_t n_big;      /* spheres decided outside the filter ... */
     int32_t big[8];     /* ... and their indices; their columns never pass */
-    int32_t n_table_rows; /* rows of the table the kernel multiplies (the other spheres along a space-filling
-                           * curve, padded to blocks of 32 and, when streamed through LDS, to tiles of 20 blocks) */
+    int32_t n_table_rows; /* rows of the table the kernel multiplies (the other spheres in the leaf order of a k-d
+                           * partition, padded to blocks of 32 and, when too long for LDS, to tiles of 20 blocks) */
 } rt_filter_info;
 int rt_filter_describe(rt_ctx *ctx, rt_filter_info *out);
 /* Filter values of n rays (origin, direction: 3 floats each, direction of any length) against every sphere,
@@ -365,6 +365,30 @@ int rt_filter_describe(rt_ctx *ctx, rt_filter_info *out);
  * the sign convention of the kernel (NEGATIVE = the sphere passes), i.e. an approximation of
  * -(disc / radius^2 + margin + margin_far * max|O'_i|).  Host pointers, synchronous. */
 int rt_filter_values_host(rt_ctx *ctx, int n_rays, const float *h_org, const float *h_dir, float *h_values);
+
+/* The filter's tables for a list of spheres, built on the HOST exactly as an upload builds them (no context, no
+ * GPU): for tests that check the tables themselves.  A table too long for LDS gets a table of bounds in front of it:
+ * one sphere around the 32 spheres of each table block, in a frame of its own (the cloud's thin axes stretched), and
+ * per bound the row of the test for what lies behind a ray; a wave then reads only the blocks whose bound some ray of
+ * it can meet.  `info` is always filled; each array may be NULL, else it receives
+ *   row_index    : n_rows ints, the sphere index behind every table row (-1: padding),
+ *   table_words  : (n_blocks + 1) * 512 words, the table in the lane layout of the matrix instruction's operand,
+ *   bound_words  : (n_bound_blocks + 1) * 768 words, the table of bounds likewise (three k-steps per block of 32).
+ * Returns RT_ERR_UNSUPPORTED for a list that gets no table.  No counterpart in the reference (its hitClosest asks
+ * every object, src/RayTracer.cpp:77-82). */
+typedef struct rt_filter_tables_info {
+    float center[3];      /* centre of both frames */
+    float scale;          /* 1024 / radius of the sphere cloud: table frame units (x 1024) per world unit */
+    float bound_scale[3]; /* the same per axis for the frame of the bounds */
+    int32_t n_rows;       /* rows of the table, padding included: 32 * (n_blocks + 1) */
+    int32_t n_blocks;     /* table blocks of 32 rows (padded to whole tiles of 20 when the table is too long for LDS) */
+    int32_t n_used;       /* ... of which hold a sphere */
+    int32_t n_bound_blocks; /* blocks of 32 bounds (0: the table stays resident in LDS and has none) */
+    int32_t n_big;        /* spheres decided outside the table ... */
+    int32_t big[8];       /* ... and their indices */
+} rt_filter_tables_info;
+int rt_filter_tables_host(int n_spheres, const rt_sphere *h_spheres, rt_filter_tables_info *info, int32_t *row_index,
+                          uint32_t *table_words, uint32_t *bound_words);
 
 /* Library/ABI version (major*100 + minor). */
 int rt_version(void);

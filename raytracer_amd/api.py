@@ -84,7 +84,7 @@ class RenderParams:
 EXPORTS = [
     "rt_version", "rt_rng4", "rt_rng4_device_host", "rt_output_rows", "rt_create", "rt_destroy", "rt_last_error",
     "rt_upload_scene", "rt_upload_scene_ex", "rt_upload_lights", "rt_set_camera", "rt_render", "rt_render_noalloc",
-    "rt_render_host", "rt_last_kernel_ms", "rt_last_kernel_variant", "rt_last_scans", "rt_last_blocks", "rt_device_allocations", "rt_filter_describe", "rt_filter_values_host",
+    "rt_render_host", "rt_last_kernel_ms", "rt_last_kernel_variant", "rt_last_scans", "rt_last_blocks", "rt_device_allocations", "rt_filter_describe", "rt_filter_values_host", "rt_filter_tables_host",
     "rt_group_create", "rt_group_destroy", "rt_group_last_error", "rt_group_size", "rt_group_transport",
     "rt_group_device_allocations", "rt_group_upload_scene_ex", "rt_group_upload_lights", "rt_group_set_camera",
     "rt_group_render", "rt_group_render_host",
@@ -95,6 +95,12 @@ class _FilterInfo(C.Structure):
     _fields_ = [("in_use", C.c_int32), ("center", C.c_float * 3), ("radius", C.c_float), ("margin", C.c_float),
                 ("margin_far", C.c_float), ("n_rows", C.c_int32), ("n_big", C.c_int32), ("big", C.c_int32 * 8),
                 ("n_table_rows", C.c_int32)]
+
+
+class _FilterTablesInfo(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("scale", C.c_float), ("bound_scale", C.c_float * 3), ("n_rows", C.c_int32),
+                ("n_blocks", C.c_int32), ("n_used", C.c_int32), ("n_bound_blocks", C.c_int32), ("n_big", C.c_int32),
+                ("big", C.c_int32 * 8)]
 
 
 _lib = None
@@ -129,6 +135,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     _proto(lib, "rt_filter_describe", "restype", C.c_int)
     _proto(lib, "rt_filter_values_host", "argtypes", [vp, C.c_int, vp, vp, vp])
     _proto(lib, "rt_filter_values_host", "restype", C.c_int)
+    _proto(lib, "rt_filter_tables_host", "argtypes", [C.c_int, vp, C.POINTER(_FilterTablesInfo), vp, vp, vp])
+    _proto(lib, "rt_filter_tables_host", "restype", C.c_int)
     _proto(lib, "rt_output_rows", "argtypes", [C.POINTER(_Params)])
     _proto(lib, "rt_output_rows", "restype", C.c_int)
     _proto(lib, "rt_create", "argtypes", [C.c_int, C.POINTER(vp)])
@@ -494,3 +502,26 @@ class Group:
         self._check(self.lib.rt_group_render_host(self.h, C.byref(cp), _ptr(rgba), C.byref(rays), C.byref(t)),
                     "rt_group_render_host")
         return rgba, int(rays.value), {f: getattr(t, f) for f, _ in _GroupTiming._fields_}
+
+
+def filter_tables(spheres: np.ndarray):
+    """The matrix-core filter's tables of a sphere list (SPHERE_DTYPE), built on the host as an upload builds them; no
+    GPU is touched.  -> dict with the frames, `row_index` (sphere behind every table row), `table` (uint32
+    [n_blocks + 1, 2, 64, 4]: block, k-step, lane, word) and `bounds` (uint32 [n_bound_blocks + 1, 3, 64, 4], or None
+    when the table stays resident in LDS), or None for a list that gets no table."""
+    lib = load_library()
+    sp = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+    info = _FilterTablesInfo()
+    rc = lib.rt_filter_tables_host(len(sp), _ptr(sp), C.byref(info), None, None, None)
+    if rc != 0:
+        return None
+    row_index = np.zeros(info.n_rows, dtype=np.int32)
+    table = np.zeros((info.n_blocks + 1, 2, 64, 4), dtype=np.uint32)
+    bounds = np.zeros((info.n_bound_blocks + 1, 3, 64, 4), dtype=np.uint32) if info.n_bound_blocks else None
+    rc = lib.rt_filter_tables_host(len(sp), _ptr(sp), C.byref(info), _ptr(row_index), _ptr(table), _ptr(bounds) if bounds is not None else None)
+    if rc != 0:
+        raise RtError(f"rt_filter_tables_host failed with code {rc}")
+    return {"center": np.array(list(info.center), dtype=np.float32), "scale": np.float32(info.scale),
+            "bound_scale": np.array(list(info.bound_scale), dtype=np.float32), "n_blocks": int(info.n_blocks),
+            "n_used": int(info.n_used), "n_bound_blocks": int(info.n_bound_blocks),
+            "big": [int(info.big[i]) for i in range(info.n_big)], "row_index": row_index, "table": table, "bounds": bounds}
