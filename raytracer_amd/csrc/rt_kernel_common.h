@@ -64,7 +64,7 @@ constexpr size_t acc_bytes_of(int src, bool full = false) {
     return (size_t)(wg_threads_of(src, full) / 64) * WAVE_LDS_WORDS * sizeof(unsigned long long);
 }
 // the variant that culls table blocks by their bounds notes per wave which blocks it wants: one word per 32 blocks
-constexpr int MF_COARSE_MAX = 48;
+constexpr int MF_COARSE_MAX = 256; // (262 144 spheres; longer tables are streamed whole)
 constexpr size_t wave_state_bytes_of(int src, bool full = false) {
     return acc_bytes_of(src, full) +
            (size_t)(wg_threads_of(src, full) / 64) * (cand_cap_of(src) * sizeof(unsigned) + 64 * sizeof(unsigned long long) +

@@ -73,6 +73,7 @@ struct MfmaFrame {
     int n_used;       // blocks that hold a sphere: what a scan of the resident table walks
     int n_coarse;     // blocks of the table of block bounds in front of a table too long for LDS (0: none)
     float csx, csy, csz; // the bounds' own frame: MF_SCALE / its radius per axis, a flat cloud's thin axes stretched (scan_mfma_culled)
+    int coarse_in_lds; // the table of bounds is resident in LDS (else, too long for that, it is read from memory like the table)
     int n_big;
     int big[MF_MAX_BIG]; // indices of the spheres decided directly
 };
@@ -365,8 +366,10 @@ __device__ __forceinline__ float16v behind_or_zero(float16v a) {
 // mfma_scan_blocks.  A block whose bound no ray's line meets holds no sphere any of the rays can hit, so the winner
 // is the one scan_mfma finds.  Whole wave, no workgroup step: the waves of a workgroup scan independently.
 // `visited` counts the blocks walked, those of the table of bounds included.
+// A table of bounds too long for LDS itself (scenes of more than about 28 000 spheres) is read from memory (`gcoarse`), one
+// block ahead of its products, like the table.
 template <int FLUSH_AT = 64, class F>
-__device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4v *__restrict__ gtab, uint32_t *wanted, const F &fr,
+__device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4v *__restrict__ gcoarse, const uint4v *__restrict__ gtab, uint32_t *wanted, const F &fr,
                                                  V3 o, V3 dh, bool live, float tmin, int self_id, int lane, const CandQ &cq,
                                                  const float4 *__restrict__ sph, const float4 *__restrict__ rows,
                                                  float &best_t, int &best_id, unsigned &visited, SecClock &sec) {
@@ -383,14 +386,10 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
         const V3 dc = ds * __frsqrt_rn(dot(ds, ds));
         const RayOperand op = mfma_ray_operand(o, dc, live, fr.cx, fr.cy, fr.cz, cs);
         const AheadOperand ah = mfma_ahead_operand(o, dc, live, fr.cx, fr.cy, fr.cz, cs);
-        const uint4v *clane = ctab + lane;
         const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-        for (int cb = 0; cb < n_coarse; ++cb) {
-            // (no read-ahead here, and one ray half at a time: this loop has no registers for a second set of table
-            // words or a second result tile beside the two operands and the path's state)
-            const half8 c0 = __builtin_bit_cast(half8, clane[(3 * cb) * 64]), c1 = __builtin_bit_cast(half8, clane[(3 * cb + 1) * 64]);
-            const half4 c2 = *reinterpret_cast<const half4 *>(clane + (3 * cb + 2) * 64); // (the first 8 bytes of the lane's word)
+        // one block of 32 bounds: which of its blocks are wanted (one ray half at a time: this loop has no registers for a
+        // second result tile beside the two operands and the path's state)
+        auto bounds_block = [&](int cb, half8 c0, half8 c1, half4 c2) {
             uint32_t w = rows_wanted(mfma_tile_onto(c0, c1, op.b[0][0], op.b[0][1], behind_or_zero(__builtin_amdgcn_mfma_f32_32x32x8f16(c2, ah.b[0], zero, 0, 0, 0))));
             __builtin_amdgcn_sched_barrier(0);
             w |= rows_wanted(mfma_tile_onto(c0, c1, op.b[1][0], op.b[1][1], behind_or_zero(__builtin_amdgcn_mfma_f32_32x32x8f16(c2, ah.b[1], zero, 0, 0, 0))));
@@ -399,6 +398,31 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
             w = cb * MF_BLOCK + MF_BLOCK <= fr.n_used ? ~0u : (1u << (fr.n_used - cb * MF_BLOCK)) - 1u;
 #endif
             if (lane == 0) wanted[cb] = w;
+        };
+        if (fr.coarse_in_lds) {
+            const uint4v *clane = ctab + lane;
+#pragma unroll 1
+            for (int cb = 0; cb < n_coarse; ++cb) // (no read-ahead from LDS: no registers for a second set of words either)
+                bounds_block(cb, __builtin_bit_cast(half8, clane[(3 * cb) * 64]), __builtin_bit_cast(half8, clane[(3 * cb + 1) * 64]),
+                             *reinterpret_cast<const half4 *>(clane + (3 * cb + 2) * 64)); // (the first 8 bytes of the lane's third word)
+        } else {
+            const __amdgpu_buffer_rsrc_t ctb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4v *>(gcoarse), 0, (n_coarse + 1) * MF_COARSE_WORDS * 16, 0x00020000);
+            const int lane_bytes = lane * 16;
+            auto words = [&](int cb, half8 &c0, half8 &c1, half4 &c2) {
+                c0 = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(ctb, lane_bytes, cb * (MF_COARSE_WORDS * 16), 0));
+                c1 = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(ctb, lane_bytes, cb * (MF_COARSE_WORDS * 16) + 1024, 0));
+                c2 = __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(ctb, lane_bytes, cb * (MF_COARSE_WORDS * 16) + 2048, 0));
+            };
+            half8 n0, n1;
+            half4 n2;
+            words(0, n0, n1, n2);
+#pragma unroll 1
+            for (int cb = 0; cb < n_coarse; ++cb) {
+                const half8 c0 = n0, c1 = n1;
+                const half4 c2 = n2;
+                words(cb + 1, n0, n1, n2); // (one more block is readable behind the last)
+                bounds_block(cb, c0, c1, c2);
+            }
         }
         visited += (unsigned)n_coarse;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

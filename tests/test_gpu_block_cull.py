@@ -46,12 +46,14 @@ def _cases():
         # the camera some 100 cloud radii out: every ray's origin term is large against the bounds
         "far": (lambda: _camera_at(_cloud("far", 2600, 10, box=box, radii=(0.2, 0.9)), (2500.0, -3000.0, 1800.0), (0.0, 0.0, 0.0)),
                 RenderParams(96, 64, 12, 20, seed=9)),
+        # 28 900 spheres: the table of bounds itself no longer fits in LDS and is read from memory like the table
+        "grid170": (lambda: scenes.by_name("grid170"), RenderParams(96, 54, 4, 30, seed=11)),
         # one more sphere than the largest table that stays resident (45 blocks): the shortest table that is cut
         "shortest": (lambda: _cloud("shortest", 1441, 8, box=(25.0, 25.0, 4.0), radii=(0.1, 0.5)), RenderParams(96, 64, 12, 12, seed=10)),
     }
 
 
-@pytest.mark.parametrize("name", ["grid10k", "grid10k_clipped", "grid64", "cloud", "offset", "inside", "far", "shortest"])
+@pytest.mark.parametrize("name", ["grid10k", "grid10k_clipped", "grid64", "cloud", "offset", "inside", "far", "grid170", "shortest"])
 def test_walking_only_the_blocks_in_reach_changes_no_byte(name, monkeypatch):
     make, p = _cases()[name]
     scene = make()
