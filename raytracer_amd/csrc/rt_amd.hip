@@ -4,7 +4,7 @@
 //   render_kernel.inc    the persistent path-trace kernel and its per-tile primary-ray lists
 //   query_kernels.inc    stage-wise kernels: filter values, first hits, scatter, random words
 //   abi_context.inc      rt_ctx, error reporting, rt_create / rt_destroy
-//   abi_scene.inc        scene / light / camera upload, the matrix-core filter's table
+//   abi_scene.inc        scene / light / camera upload, the matrix-core filter's table and, for long tables, its blocks' bounds
 //   abi_render.inc       rt_render, rt_render_host: work-item shape, variant and grid of a launch
 //   abi_query.inc        rt_first_hit*, rt_scatter_host, rt_rng4*, rt_filter_*
 //   abi_group.inc        rt_group_*: one frame on several GPUs of one process (rccl_api.h binds RCCL)
