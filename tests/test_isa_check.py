@@ -61,3 +61,20 @@ def test_render_kernels_with_scratch_memory_are_refused():
            "\t.amdhsa_kernel _Z16first_hit_kernelILb1EEv\n\t.end_amdhsa_kernel\n" + info("Kernel", 256))
     found = check_isa.scratch_users(asm)
     assert len(found) == 1 and "ILi2ELb0" in found[0] and "12" in found[0]
+
+
+def test_packed_fp32_with_an_sgpr_pair_and_op_sel_is_refused():
+    """The form that returned wrong lanes on the GPU (tools/hazard_pk.hip) is reported wherever it stands; the same
+    instruction with VGPR sources, or with an SGPR pair in the plain pairing, is not."""
+    asm = ("k1:                                    ; @k1\n"
+           "\tv_pk_fma_f32 v[6:7], s[4:5], v[6:7], v[4:5] op_sel:[1,0,1] op_sel_hi:[0,0,0]\n"
+           "\tv_pk_mul_f32 v[28:29], s[64:65], v[4:5] op_sel:[1,0] op_sel_hi:[0,1]\n"
+           "\tv_pk_fma_f32 v[6:7], v[8:9], v[6:7], v[4:5] op_sel:[1,0,1] op_sel_hi:[0,0,0]\n"
+           "\tv_pk_fma_f32 v[6:7], s[4:5], v[6:7], v[4:5]\n"
+           "\tv_pk_fma_f32 v[42:43], v[40:41], s[20:21], v[4:5] op_sel_hi:[1,1,1]\n"
+           "\tv_pk_add_f32 v[4:5], s[18:19], v[4:5] neg_lo:[0,1] neg_hi:[0,1]\n"
+           "\tv_pk_mul_f32 v[38:39], s[10:11], v[6:7] op_sel_hi:[1,0]\n"
+           "\ts_endpgm\n.end_amdhsa_kernel\n")
+    found = check_isa.packed_sgpr_opsel(asm)
+    assert len(found) == 3, found
+    assert "op_sel:[1,0,1]" in found[0] and "s[64:65]" in found[1] and "op_sel_hi:[1,0]" in found[2]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Checks the compiled gfx950 code for one hazard the compiler cannot see.
+"""Checks the compiled gfx950 code for hazards the compiler does not see.
 
 The scan loop of the render kernel requests sphere words with inline-asm scalar loads and waits for
 them later, with compiler-scheduled code in between (that overlap is the point).  To the compiler the
@@ -9,7 +9,10 @@ assembly, follows every path of each kernel's control-flow graph, and fails if a
 can execute between such a load and the next inline-asm `s_waitcnt lgkmcnt(0)` touches one of the
 load's destination registers.
 
-It also refuses a build in which a render kernel spills registers to scratch memory (scratch_users).
+It also refuses a build in which a render kernel spills registers to scratch memory (scratch_users), and one
+in which any kernel holds a packed FP32 instruction that takes an SGPR pair as a source and re-routes halves with
+op_sel (packed_sgpr_opsel): on gfx950 that form returned wrong low results in lanes 48-63 whenever other waves of
+the CU were running matrix instructions (tools/hazard_pk.hip reproduces it).
 
 usage: check_isa.py [file.s]     (without a file: compiles raytracer_amd/csrc/rt_amd.hip to assembly first)
 """
@@ -28,7 +31,7 @@ def device_asm() -> str:
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "rt_amd.s")
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                               "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
+                               "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
         return open(out).read()
 
 
@@ -141,12 +144,44 @@ def scratch_users(asm: str) -> list:
     return found
 
 
+def packed_sgpr_opsel(asm: str) -> list:
+    """Packed FP32 instructions (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32) with an SGPR pair among their sources and an
+    op_sel / op_sel_hi that is not the plain pairing (low halves -> low result, high halves -> high result).  Measured
+    on MI355X: `v_pk_fma_f32 v[d:d+1], s[a:a+1], v[b:b+1], v[c:c+1] op_sel:[1,0,1] op_sel_hi:[0,0,0]` gives a low result
+    of 0 instead of s[a+1] * v[b] + v[c+1] in lanes 48-63 now and then, only while other waves of the CU issue MFMAs; the same with
+    VGPR sources, or with the SGPR pair and no op_sel, never did.  The compiler's SLP vectoriser emits the form; the
+    build switches that pass off, and this check keeps it from coming back unseen."""
+    found, name = [], None
+    for n, raw in enumerate(asm.splitlines(), 1):
+        m = re.match(r"^(\w+):\s*; @\1", raw)
+        if m:
+            name = m.group(1)
+        line = raw.split(";")[0].strip()
+        m = re.match(r"v_pk_(fma|mul|add)_f32\S*\s+(.*)", line)
+        if not m or not re.search(r"\bs\[\d+:\d+\]", m.group(2)):
+            continue
+        nsrc = 3 if m.group(1) == "fma" else 2
+        sel = re.search(r"\bop_sel:\[([\d,]+)\]", line)
+        sel_hi = re.search(r"\bop_sel_hi:\[([\d,]+)\]", line)
+        plain = (sel is None or set(sel.group(1).split(",")) == {"0"}) and \
+                (sel_hi is None or sel_hi.group(1).split(",")[:nsrc] == ["1"] * nsrc)
+        if not plain:
+            found.append(f"{name}: line {n}: '{line}'")
+    return found
+
+
 def main() -> int:
     asm = open(sys.argv[1]).read() if len(sys.argv) > 1 else device_asm()
     spilled = scratch_users(asm)
     for s in spilled:
         print("render kernel with scratch memory:", s)
     if spilled and not os.environ.get("RT_ALLOW_SCRATCH"):  # tuning builds (-DRT_STATS ...) may set this
+        return 1
+    risky = packed_sgpr_opsel(asm)
+    for r in risky[:20]:
+        print("packed FP32 with an SGPR pair and op_sel:", r)
+    if risky:
+        print(f"{len(risky)} packed FP32 instruction(s) of the form that returns wrong lanes beside matrix instructions")
         return 1
     problems = check(asm)
     for p in problems[:40]:
