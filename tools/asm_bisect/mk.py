@@ -1,7 +1,7 @@
 """Debug aid: variants of the library whose device code is edited at assembly level (wait states, register checks)
 and assembled again, so that a fault which any change of the source makes disappear can be narrowed down.
 How it was used (paths are this tool's own, under /tmp/asmbis):
-  hipcc -v <the build's flags> -DRT_MF_PROBE_FULL_LISTS -save-temps=obj -o lib.so raytracer_amd/csrc/rt_amd.hip > build.log 2>&1
+  hipcc -v <the flags of the build as it was then, SLP vectoriser on> -DRT_MF_PROBE_FULL_LISTS (a probe switch of that time) -save-temps=obj -o lib.so raytracer_amd/csrc/rt_amd.hip > build.log 2>&1
   rebuild.sh = the sub-commands of build.log from the device assembler on (clang -cc1as of the gfx950 .s, lld,
   clang-offload-bundler, the host compile with the new bundle, the link); dev_orig.s = the device assembly as compiled.
 Each variant below inserts lines at kernel-local line numbers of render_kernel<5, true> in dev_orig.s (BASE = the
