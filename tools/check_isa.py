@@ -147,10 +147,12 @@ def scratch_users(asm: str) -> list:
 def packed_sgpr_opsel(asm: str) -> list:
     """Packed FP32 instructions (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32) with an SGPR pair among their sources and an
     op_sel / op_sel_hi that is not the plain pairing (low halves -> low result, high halves -> high result).  Measured
-    on MI355X: `v_pk_fma_f32 v[d:d+1], s[a:a+1], v[b:b+1], v[c:c+1] op_sel:[1,0,1] op_sel_hi:[0,0,0]` gives a low result
-    of 0 instead of s[a+1] * v[b] + v[c+1] in lanes 48-63 now and then, only while other waves of the CU issue MFMAs; the same with
-    VGPR sources, or with the SGPR pair and no op_sel, never did.  The compiler's SLP vectoriser emits the form; the
-    build switches that pass off, and this check keeps it from coming back unseen."""
+    on MI355X (tools/hazard_pk.hip): in `v_pk_fma_f32 v[d:d+1], s[a:a+1], v[b:b+1], v[c:c+1] op_sel:[1,0,1] op_sel_hi:[0,0,0]`
+    the addend of the low result, which op_sel takes from the high half of the third source, reads as 0 in lanes 48-63
+    now and then, only while other waves of the CU issue MFMAs, and only when an SGPR pair is among the sources and
+    op_sel re-routes the third one; VGPR sources throughout, or the plain pairing, never did.  The compiler's SLP
+    vectoriser emits the form; the build switches that pass off, and this check keeps it from coming back unseen (it
+    refuses every re-routing beside an SGPR pair, not only the combinations that were seen to fail)."""
     found, name = [], None
     for n, raw in enumerate(asm.splitlines(), 1):
         m = re.match(r"^(\w+):\s*; @\1", raw)
