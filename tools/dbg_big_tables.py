@@ -1,3 +1,5 @@
+"""Debug aid: grids of tens of thousands of spheres (tables of bounds too long for LDS) with the table walked where its
+bounds are met and streamed whole: times, blocks walked, frame hashes."""
 import os, sys, hashlib
 sys.path.insert(0, '.')
 import numpy as np

@@ -1,3 +1,5 @@
+"""Tuning aid: the turn counters of a -DRT_STATS build (tools/v_stats.so) for one render: turns with and without a scan,
+decided primary rays and waiting lanes per turn."""
 import ctypes as C, os, sys
 sys.path.insert(0, '.')
 os.environ["RT_AMD_LIB"] = os.path.abspath("tools/v_stats.so")
