@@ -332,18 +332,21 @@ __device__ __forceinline__ AheadOperand mfma_ahead_operand(V3 o, V3 dh, bool liv
 }
 
 // Which rows of a block of bounds are wanted by ANY ray of one half of the wave's rays: a negative value.  Bit b = row b
-// of the block (register v of lanes 0-31 is row v, of lanes 32-63 row 16 + v, see mfma_tile).  Wave-uniform; the lane
-// masks of the comparisons are taken apart on the scalar unit.
+// of the block (register v of lanes 0-31 is row v, of lanes 32-63 row 16 + v, see mfma_tile).  Wave-uniform.
 __device__ __forceinline__ uint32_t rows_wanted(const float16v &m) {
-    uint32_t rows = 0;
+    // the lane's sixteen sign bits (bit v = register v), one v_alignbit_b32 each ...
+    uint32_t mask = 0;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        unsigned long long b = __ballot((int)__float_as_uint(m[v]) < 0);
-        asm("" : "+s"(b)); // a scalar register pair from here on: its halves are tested with scalar compares
-        const uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
-        rows |= (lo != 0u ? 1u << v : 0u) | (hi != 0u ? 1u << (16 + v) : 0u);
-    }
-    return rows;
+    for (int v = 15; v >= 0; --v) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(m[v]), 31);
+    // ... OR-ed over the 32 lanes of each ray half: within rows of sixteen lanes by shifts of 1, 2, 4, 8 (a lane beyond the
+    // row's start contributes 0), then row 0's last lane into row 1 and row 2's into row 3; lanes 31 and 63 hold the halves
+    mask |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mask, 0x111, 0xf, 0xf, true); // row_shr:1
+    mask |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mask, 0x112, 0xf, 0xf, true); // row_shr:2
+    mask |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mask, 0x114, 0xf, 0xf, true); // row_shr:4
+    mask |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mask, 0x118, 0xf, 0xf, true); // row_shr:8
+    mask |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mask, 0x142, 0xa, 0xf, true); // row_bcast:15 into rows 1 and 3
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)mask, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)mask, 63);
+    return lo | (hi << 16);
 }
 // How far a bound lies behind a ray's origin, or zero: what the filter's products for the bound are added to.
 __device__ __forceinline__ float16v behind_or_zero(float16v a) {
@@ -390,9 +393,17 @@ __device__ __forceinline__ void scan_mfma_culled(const uint4v *ctab, const uint4
         // one block of 32 bounds: which of its blocks are wanted (one ray half at a time: this loop has no registers for a
         // second result tile beside the two operands and the path's state)
         auto bounds_block = [&](int cb, half8 c0, half8 c1, half4 c2) {
-            uint32_t w = rows_wanted(mfma_tile_onto(c0, c1, op.b[0][0], op.b[0][1], behind_or_zero(__builtin_amdgcn_mfma_f32_32x32x8f16(c2, ah.b[0], zero, 0, 0, 0))));
+            // (a half of the rays that wants none of the 32 bounds -- no negative value in any lane -- skips the gather of the signs)
+            uint32_t w = 0;
+            {
+                const float16v t = mfma_tile_onto(c0, c1, op.b[0][0], op.b[0][1], behind_or_zero(__builtin_amdgcn_mfma_f32_32x32x8f16(c2, ah.b[0], zero, 0, 0, 0)));
+                if (__ballot((int)or16(t) < 0) != 0) w = rows_wanted(t);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            w |= rows_wanted(mfma_tile_onto(c0, c1, op.b[1][0], op.b[1][1], behind_or_zero(__builtin_amdgcn_mfma_f32_32x32x8f16(c2, ah.b[1], zero, 0, 0, 0))));
+            {
+                const float16v t = mfma_tile_onto(c0, c1, op.b[1][0], op.b[1][1], behind_or_zero(__builtin_amdgcn_mfma_f32_32x32x8f16(c2, ah.b[1], zero, 0, 0, 0)));
+                if (__ballot((int)or16(t) < 0) != 0) w |= rows_wanted(t);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #ifdef RT_MF_PROBE_WANT_ALL // tuning probe: every block is walked (the words past the table's end are rows that never pass)
             w = cb * MF_BLOCK + MF_BLOCK <= fr.n_used ? ~0u : (1u << (fr.n_used - cb * MF_BLOCK)) - 1u;
